@@ -1,0 +1,98 @@
+"""ctypes binding of libcapdec.so (include/capdec.h).  Fails loudly when the library is missing.
+
+There is no CPU fallback anywhere in this package: every op goes through this module, and a
+missing / unloadable ``libcapdec.so`` raises at first use.
+"""
+import ctypes as C
+import os
+
+import torch
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libcapdec.so")
+
+F32, BF16 = 0, 1
+ACT_NONE, ACT_GELU, ACT_GELU_BWD = 0, 1, 2
+
+_vp, _i, _f, _u64, _sz = C.c_void_p, C.c_int, C.c_float, C.c_uint64, C.c_size_t
+
+
+class Epilogue(C.Structure):
+    _fields_ = [("bias", _vp), ("addend", _vp), ("pre", _vp), ("aux", _vp), ("colsum", _vp),
+                ("ld_addend", _i), ("act", _i), ("drop_p", _f), ("drop_seed", _u64)]
+
+
+# name -> (restype, argtypes); mirrors include/capdec.h one to one
+SIGNATURES = {
+    "capdec_abi_version": (_i, []),
+    "capdec_last_error": (C.c_char_p, []),
+    "capdec_gemm_workspace_bytes": (_sz, [_i, _i, _i]),
+    "capdec_gemm": (_i, [_i, _i, _i, _i, _i, _vp, _i, _vp, _i, _vp, _i, C.POINTER(Epilogue), _i, _vp, _sz, _vp]),
+    "capdec_layernorm_bwd_workspace_bytes": (_sz, [_i, _i]),
+    "capdec_layernorm_fwd": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _f, _i, _f, _u64, _vp]),
+    "capdec_layernorm_bwd": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _f, _u64, _f, _u64,
+                                  _vp, _sz, _vp]),
+    "capdec_embed_fwd": (_i, [_vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _f, _u64, _vp]),
+    "capdec_embed_bwd_workspace_bytes": (_sz, [_i]),
+    "capdec_embed_bwd": (_i, [_vp, _vp, _vp, _i, _i, _i, _i, _f, _u64, _vp, _sz, _vp]),
+    "capdec_attn_fwd": (_i, [_vp, _i, _vp, _i, _vp, _i, _vp, _i, _vp, _i, _i, _i, _i, _i, _i, _f, _f, _u64, _vp]),
+    "capdec_attn_bwd": (_i, [_vp, _i, _vp, _i, _vp, _i, _vp, _i, _vp, _i, _vp, _vp, _vp, _i, _vp, _i, _vp, _i,
+                             _i, _i, _i, _i, _i, _i, _f, _f, _u64, _vp]),
+    "capdec_softmax_ce": (_i, [_vp, _i, _vp, _vp, _vp, _i, _i, _i, _f, _f, _vp]),
+    "capdec_reduce_workspace_bytes": (_sz, []),
+    "capdec_sum": (_i, [_vp, _sz, _f, _vp, _vp, _sz, _vp]),
+    "capdec_sumsq": (_i, [_vp, _sz, _vp, _vp, _sz, _vp]),
+    "capdec_clip_scale": (_i, [_vp, _sz, _vp, _f, _vp]),
+    "capdec_adamw": (_i, [_vp, _vp, _vp, _vp, _sz, _f, _f, _f, _f, _f, _i, _vp, _f, _vp]),
+    "capdec_pe_add": (_i, [_vp, _vp, _vp, _i, _i, _i, _i, _i, _f, _u64, _vp]),
+    "capdec_act_dropout_bwd": (_i, [_vp, _vp, _vp, _sz, _f, _u64, _vp]),
+}
+
+_lib = None
+
+
+def lib():
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise RuntimeError(
+                f"{LIB_PATH} is missing: build it with `python -m imagecaption_amd.build` "
+                "(hipcc --offload-arch=gfx950).  There is no CPU / PyTorch fallback for the capdec ops.")
+        l = C.CDLL(LIB_PATH)
+        for name, (res, args) in SIGNATURES.items():
+            fn = getattr(l, name)  # AttributeError if the .so does not export a declared symbol
+            fn.restype, fn.argtypes = res, args
+        _lib = l
+    return _lib
+
+
+class CapdecError(RuntimeError):
+    pass
+
+
+def check(rc, what=""):
+    if rc != 0:
+        msg = lib().capdec_last_error().decode("utf-8", "replace")
+        raise CapdecError(f"{what or 'capdec'} failed (code {rc}): {msg}")
+
+
+def ptr(t):
+    return None if t is None else t.data_ptr()
+
+
+def stream():
+    return torch.cuda.current_stream().cuda_stream
+
+
+# ---- per-device scratch workspace (borrowed by the C ABI; grown on demand, never inside capture) ----
+_ws = {}
+
+
+def workspace(nbytes, device):
+    key = (device.type, device.index)
+    w = _ws.get(key)
+    if w is None or w.numel() < nbytes:
+        size = max(int(nbytes), 64 << 20)
+        w = torch.empty(size, dtype=torch.uint8, device=device)
+        _ws[key] = w
+    return w

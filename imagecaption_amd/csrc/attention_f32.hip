@@ -1,0 +1,431 @@
+// Fused attention (scores + softmax + context) for the caption decoder, fp32 on the gfx950 matrix
+// cores (v_mfma_f32_32x32x2_f32), forward and flash-style backward.  See include/capdec.h.
+//
+// One wave (64-thread workgroup) owns one (batch, head, 32-row tile); nothing crosses workgroups,
+// so there are no atomics and results are bitwise reproducible.
+//   forward / dQ : the wave owns 32 queries and walks 32-key tiles.  It computes S^T = K Q^T, so a
+//                  lane holds 16 scores of ONE query (its partner lane^32 the other 16): the softmax
+//                  row reduction is 15 fmax + one cross-half shuffle.  The S^T accumulator registers
+//                  are then fed straight back as the A operand of P V (or dS K): MFMA sums over the
+//                  accumulator's row index (the key), so no lane movement and no LDS round trip.
+//   dK / dV      : the wave owns 32 keys and walks 32-query tiles with S = Q K^T (query on the
+//                  accumulator rows), whose registers are the A operand of P^T dO and dS^T Q.
+// K/V (or Q/dO) tiles are staged through LDS as [row][dh+4]: the +4 padding makes the 16-lane
+// ds_read_b128 groups of the "row on lane" operand reads bank-conflict free, and the same image
+// serves the "row from register index" reads (32 consecutive dwords per half-wave).
+// Per-query scalars (softmax rescale, 1/l, lse, delta) reach the register-row layout through a
+// 32-float LDS line read back as four float4.
+#include "common.h"
+
+namespace capdec {
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+
+struct AttnParams {
+    const float* q; const float* k; const float* v; const float* o; const float* dout;
+    float* out; float* lse; float* delta; float* dq; float* dk; float* dv;
+    int ldq, ldk, ldv, ldo, lddo, lddq, lddk, lddv;
+    int B, H, Tq, Tk, causal;
+    float scale;
+    Dropout drop;
+};
+
+__device__ __forceinline__ int row_of(int r, int half) { return (r & 3) + 8 * (r >> 2) + 4 * half; }
+
+template <int DH>
+__device__ __forceinline__ void load_tile(float* s, const float* g, int ldg, int row0, int T, float mul, int lane) {
+    constexpr int LD = DH + 4;
+#pragma unroll
+    for (int i = 0; i < DH / 8; ++i) {
+        const int f = lane + 64 * i;
+        const int row = f / (DH / 4), c4 = f % (DH / 4);
+        const int t = row0 + row;
+        float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (t < T) v = *reinterpret_cast<const float4*>(g + (size_t)t * ldg + c4 * 4);
+        v.x *= mul; v.y *= mul; v.z *= mul; v.w *= mul;
+        *reinterpret_cast<float4*>(&s[row * LD + c4 * 4]) = v;
+    }
+}
+
+// fragment of the "row on lane" operand: row = lane&31, k = 8*jj + 4*half + c
+template <int DH>
+__device__ __forceinline__ void load_frag_global(float4* f, const float* g, int ldg, int row, int T, float mul, int half) {
+#pragma unroll
+    for (int jj = 0; jj < DH / 8; ++jj) {
+        float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (row < T) v = *reinterpret_cast<const float4*>(g + (size_t)row * ldg + 8 * jj + 4 * half);
+        v.x *= mul; v.y *= mul; v.z *= mul; v.w *= mul;
+        f[jj] = v;
+    }
+}
+
+// acc += A(lds rows on lanes) * B(register fragment)^T  over the head dimension
+template <int DH>
+__device__ __forceinline__ f32x16 mma_lds_reg(const float* s, const float4* bf, int l31, int half) {
+    constexpr int LD = DH + 4;
+    f32x16 acc;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+#pragma unroll
+    for (int jj = 0; jj < DH / 8; ++jj) {
+        const float4 a = *reinterpret_cast<const float4*>(&s[l31 * LD + 8 * jj + 4 * half]);
+        acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a.x, bf[jj].x, acc, 0, 0, 0);
+        acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a.y, bf[jj].y, acc, 0, 0, 0);
+        acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a.z, bf[jj].z, acc, 0, 0, 0);
+        acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a.w, bf[jj].w, acc, 0, 0, 0);
+    }
+    return acc;
+}
+// acc = A(register fragment) * B(lds rows on lanes)^T
+template <int DH>
+__device__ __forceinline__ f32x16 mma_reg_lds(const float4* af, const float* s, int l31, int half) {
+    constexpr int LD = DH + 4;
+    f32x16 acc;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+#pragma unroll
+    for (int jj = 0; jj < DH / 8; ++jj) {
+        const float4 b = *reinterpret_cast<const float4*>(&s[l31 * LD + 8 * jj + 4 * half]);
+        acc = __builtin_amdgcn_mfma_f32_32x32x2f32(af[jj].x, b.x, acc, 0, 0, 0);
+        acc = __builtin_amdgcn_mfma_f32_32x32x2f32(af[jj].y, b.y, acc, 0, 0, 0);
+        acc = __builtin_amdgcn_mfma_f32_32x32x2f32(af[jj].z, b.z, acc, 0, 0, 0);
+        acc = __builtin_amdgcn_mfma_f32_32x32x2f32(af[jj].w, b.w, acc, 0, 0, 0);
+    }
+    return acc;
+}
+// out[dt] += X^T * S  where X = accumulator-layout tile x[16] (rows = its register index) and S
+// is an LDS image whose row index matches X's row index.
+template <int DH>
+__device__ __forceinline__ void mma_acc_lds(f32x16* out, const float* x, const float* s, int l31, int half) {
+    constexpr int LD = DH + 4;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+        const float* srow = s + row_of(r, half) * LD + l31;
+#pragma unroll
+        for (int dt = 0; dt < DH / 32; ++dt)
+            out[dt] = __builtin_amdgcn_mfma_f32_32x32x2f32(x[r], srow[dt * 32], out[dt], 0, 0, 0);
+    }
+}
+
+// spread a per-lane-row scalar (valid in lanes 0..31, row = lane) to the register-row layout
+__device__ __forceinline__ void spread_rows(float* line, float val, float* outv, int lane, int half) {
+    __syncthreads();
+    if (lane < 32) line[lane] = val;
+    __syncthreads();
+#pragma unroll
+    for (int g = 0; g < 4; ++g) {
+        const float4 t = *reinterpret_cast<const float4*>(&line[8 * g + 4 * half]);
+        outv[4 * g + 0] = t.x; outv[4 * g + 1] = t.y; outv[4 * g + 2] = t.z; outv[4 * g + 3] = t.w;
+    }
+}
+
+template <int DH>
+__global__ __launch_bounds__(64) void attn_fwd_kernel(AttnParams p) {
+    constexpr int LD = DH + 4;
+    __shared__ __attribute__((aligned(16))) float Ks[32 * LD];
+    __shared__ __attribute__((aligned(16))) float Vs[32 * LD];
+    __shared__ __attribute__((aligned(16))) float line[32];
+    const int lane = threadIdx.x, l31 = lane & 31, half = lane >> 5;
+    const int nqt = (p.Tq + 31) / 32;
+    const int qt = blockIdx.x % nqt, bh = blockIdx.x / nqt;
+    const int b = bh / p.H, h = bh % p.H;
+    const int q0 = qt * 32, off = p.Tk - p.Tq;
+    const float* qg = p.q + (size_t)b * p.Tq * p.ldq + h * DH;
+    const float* kg = p.k + (size_t)b * p.Tk * p.ldk + h * DH;
+    const float* vg = p.v + (size_t)b * p.Tk * p.ldv + h * DH;
+
+    float4 qf[DH / 8];
+    load_frag_global<DH>(qf, qg, p.ldq, q0 + l31, p.Tq, p.scale, half);
+    f32x16 oacc[DH / 32];
+#pragma unroll
+    for (int dt = 0; dt < DH / 32; ++dt)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) oacc[dt][r] = 0.f;
+    float m_run = -INFINITY, l_run = 0.f;
+    const int query = q0 + l31;
+    int kmax = p.Tk;
+    if (p.causal) kmax = min(p.Tk, q0 + 31 + off + 1);
+    const int nkt = kmax > 0 ? (kmax + 31) / 32 : 0;
+    for (int kt = 0; kt < nkt; ++kt) {
+        const int k0 = kt * 32;
+        __syncthreads();
+        load_tile<DH>(Ks, kg, p.ldk, k0, p.Tk, 1.f, lane);
+        load_tile<DH>(Vs, vg, p.ldv, k0, p.Tk, 1.f, lane);
+        __syncthreads();
+        f32x16 s = mma_lds_reg<DH>(Ks, qf, l31, half);
+        float mloc = -INFINITY;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int key = k0 + row_of(r, half);
+            const bool vis = key < p.Tk && (!p.causal || key <= query + off);
+            s[r] = vis ? s[r] : -INFINITY;
+            mloc = fmaxf(mloc, s[r]);
+        }
+        mloc = fmaxf(mloc, __shfl_xor(mloc, 32, 64));
+        const float m_new = fmaxf(m_run, mloc);
+        const float m_use = m_new == -INFINITY ? 0.f : m_new;
+        const float alpha = __expf(m_run - m_use);  // m_run = -inf -> 0
+        float pr[16];
+        float lsum = 0.f;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            pr[r] = __expf(s[r] - m_use);
+            lsum += pr[r];
+        }
+        lsum += __shfl_xor(lsum, 32, 64);
+        l_run = l_run * alpha + lsum;
+        m_run = m_new;
+        if (p.drop.on()) {
+            const uint32_t base = ((uint32_t)bh * (uint32_t)p.Tq + (uint32_t)query) * (uint32_t)p.Tk + (uint32_t)k0;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) pr[r] = p.drop.apply(pr[r], base + (uint32_t)row_of(r, half));
+        }
+        float arow[16];
+        spread_rows(line, alpha, arow, lane, half);
+#pragma unroll
+        for (int dt = 0; dt < DH / 32; ++dt)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) oacc[dt][r] *= arow[r];
+        mma_acc_lds<DH>(oacc, pr, Vs, l31, half);
+    }
+    const float inv = l_run > 0.f ? 1.f / l_run : 0.f;
+    float irow[16];
+    spread_rows(line, inv, irow, lane, half);
+    float* og = p.out + (size_t)b * p.Tq * p.ldo + h * DH;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+        const int qq = q0 + row_of(r, half);
+        if (qq < p.Tq) {
+#pragma unroll
+            for (int dt = 0; dt < DH / 32; ++dt) og[(size_t)qq * p.ldo + dt * 32 + l31] = oacc[dt][r] * irow[r];
+        }
+    }
+    if (p.lse && lane < 32 && query < p.Tq)
+        p.lse[(size_t)bh * p.Tq + query] = l_run > 0.f ? m_run + __logf(l_run) : INFINITY;
+}
+
+// dQ (and delta = rowsum(dO * O)); wave owns 32 queries.
+template <int DH>
+__global__ __launch_bounds__(64) void attn_bwd_dq_kernel(AttnParams p) {
+    constexpr int LD = DH + 4;
+    __shared__ __attribute__((aligned(16))) float Ks[32 * LD];
+    __shared__ __attribute__((aligned(16))) float Vs[32 * LD];
+    const int lane = threadIdx.x, l31 = lane & 31, half = lane >> 5;
+    const int nqt = (p.Tq + 31) / 32;
+    const int qt = blockIdx.x % nqt, bh = blockIdx.x / nqt;
+    const int b = bh / p.H, h = bh % p.H;
+    const int q0 = qt * 32, off = p.Tk - p.Tq;
+    const int query = q0 + l31;
+    const float* qg = p.q + (size_t)b * p.Tq * p.ldq + h * DH;
+    const float* kg = p.k + (size_t)b * p.Tk * p.ldk + h * DH;
+    const float* vg = p.v + (size_t)b * p.Tk * p.ldv + h * DH;
+    const float* og = p.o + (size_t)b * p.Tq * p.ldo + h * DH;
+    const float* dog = p.dout + (size_t)b * p.Tq * p.lddo + h * DH;
+
+    float4 qf[DH / 8], dof[DH / 8];
+    load_frag_global<DH>(qf, qg, p.ldq, query, p.Tq, p.scale, half);
+    load_frag_global<DH>(dof, dog, p.lddo, query, p.Tq, 1.f, half);
+    float dsum = 0.f;
+    if (query < p.Tq) {
+#pragma unroll
+        for (int jj = 0; jj < DH / 8; ++jj) {
+            const float4 ov = *reinterpret_cast<const float4*>(og + (size_t)query * p.ldo + 8 * jj + 4 * half);
+            dsum += (dof[jj].x * ov.x + dof[jj].y * ov.y) + (dof[jj].z * ov.z + dof[jj].w * ov.w);
+        }
+    }
+    dsum += __shfl_xor(dsum, 32, 64);
+    const float lse = query < p.Tq ? p.lse[(size_t)bh * p.Tq + query] : INFINITY;
+    if (lane < 32 && query < p.Tq) p.delta[(size_t)bh * p.Tq + query] = dsum;
+
+    f32x16 dqacc[DH / 32];
+#pragma unroll
+    for (int dt = 0; dt < DH / 32; ++dt)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) dqacc[dt][r] = 0.f;
+    int kmax = p.Tk;
+    if (p.causal) kmax = min(p.Tk, q0 + 31 + off + 1);
+    const int nkt = kmax > 0 ? (kmax + 31) / 32 : 0;
+    for (int kt = 0; kt < nkt; ++kt) {
+        const int k0 = kt * 32;
+        __syncthreads();
+        load_tile<DH>(Ks, kg, p.ldk, k0, p.Tk, 1.f, lane);
+        load_tile<DH>(Vs, vg, p.ldv, k0, p.Tk, 1.f, lane);
+        __syncthreads();
+        f32x16 s = mma_lds_reg<DH>(Ks, qf, l31, half);    // S^T[key][query]
+        f32x16 dp = mma_lds_reg<DH>(Vs, dof, l31, half);  // dP^T[key][query]
+        float ds[16];
+        const uint32_t base = ((uint32_t)bh * (uint32_t)p.Tq + (uint32_t)query) * (uint32_t)p.Tk + (uint32_t)k0;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int key = k0 + row_of(r, half);
+            const bool vis = key < p.Tk && (!p.causal || key <= query + off);
+            const float pv = vis ? __expf(s[r] - lse) : 0.f;
+            float g = dp[r];
+            if (p.drop.on()) g = p.drop.apply(g, base + (uint32_t)row_of(r, half));
+            ds[r] = pv * (g - dsum);
+        }
+        mma_acc_lds<DH>(dqacc, ds, Ks, l31, half);
+    }
+    float* dqg = p.dq + (size_t)b * p.Tq * p.lddq + h * DH;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+        const int qq = q0 + row_of(r, half);
+        if (qq < p.Tq) {
+#pragma unroll
+            for (int dt = 0; dt < DH / 32; ++dt) dqg[(size_t)qq * p.lddq + dt * 32 + l31] = dqacc[dt][r] * p.scale;
+        }
+    }
+}
+
+// dK, dV; wave owns 32 keys.  Must run after attn_bwd_dq_kernel (reads delta).
+template <int DH>
+__global__ __launch_bounds__(64) void attn_bwd_dkv_kernel(AttnParams p) {
+    constexpr int LD = DH + 4;
+    __shared__ __attribute__((aligned(16))) float Qs[32 * LD];
+    __shared__ __attribute__((aligned(16))) float dOs[32 * LD];
+    __shared__ __attribute__((aligned(16))) float lse_s[32];
+    __shared__ __attribute__((aligned(16))) float del_s[32];
+    const int lane = threadIdx.x, l31 = lane & 31, half = lane >> 5;
+    const int nkt = (p.Tk + 31) / 32;
+    const int kt = blockIdx.x % nkt, bh = blockIdx.x / nkt;
+    const int b = bh / p.H, h = bh % p.H;
+    const int k0 = kt * 32, off = p.Tk - p.Tq;
+    const int key = k0 + l31;
+    const float* qg = p.q + (size_t)b * p.Tq * p.ldq + h * DH;
+    const float* kg = p.k + (size_t)b * p.Tk * p.ldk + h * DH;
+    const float* vg = p.v + (size_t)b * p.Tk * p.ldv + h * DH;
+    const float* dog = p.dout + (size_t)b * p.Tq * p.lddo + h * DH;
+
+    float4 kf[DH / 8], vf[DH / 8];
+    load_frag_global<DH>(kf, kg, p.ldk, key, p.Tk, 1.f, half);
+    load_frag_global<DH>(vf, vg, p.ldv, key, p.Tk, 1.f, half);
+    f32x16 dkacc[DH / 32], dvacc[DH / 32];
+#pragma unroll
+    for (int dt = 0; dt < DH / 32; ++dt)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) dkacc[dt][r] = dvacc[dt][r] = 0.f;
+    // causal: queries q with key <= q + off  <=>  q >= key - off; first useful tile holds q = k0 - off
+    int qstart = 0;
+    if (p.causal) {
+        const int qmin = k0 - off;
+        qstart = qmin > 0 ? (qmin / 32) : 0;
+    }
+    const int nqt = (p.Tq + 31) / 32;
+    for (int qt = qstart; qt < nqt; ++qt) {
+        const int q0 = qt * 32;
+        __syncthreads();
+        load_tile<DH>(Qs, qg, p.ldq, q0, p.Tq, p.scale, lane);
+        load_tile<DH>(dOs, dog, p.lddo, q0, p.Tq, 1.f, lane);
+        if (lane < 32) {
+            const int qq = q0 + lane;
+            lse_s[lane] = qq < p.Tq ? p.lse[(size_t)bh * p.Tq + qq] : INFINITY;
+            del_s[lane] = qq < p.Tq ? p.delta[(size_t)bh * p.Tq + qq] : 0.f;
+        }
+        __syncthreads();
+        f32x16 s = mma_lds_reg<DH>(Qs, kf, l31, half);    // S[query][key]
+        f32x16 dp = mma_lds_reg<DH>(dOs, vf, l31, half);  // dP[query][key]
+        float pd[16], ds[16];
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+            const float4 lv = *reinterpret_cast<const float4*>(&lse_s[8 * g + 4 * half]);
+            const float4 dv = *reinterpret_cast<const float4*>(&del_s[8 * g + 4 * half]);
+            const float la[4] = {lv.x, lv.y, lv.z, lv.w};
+            const float da[4] = {dv.x, dv.y, dv.z, dv.w};
+#pragma unroll
+            for (int c = 0; c < 4; ++c) {
+                const int r = 4 * g + c;
+                const int qq = q0 + row_of(r, half);
+                const bool vis = key < p.Tk && qq < p.Tq && (!p.causal || key <= qq + off);
+                const float pv = vis ? __expf(s[r] - la[c]) : 0.f;
+                float pdr = pv, gr = dp[r];
+                if (p.drop.on()) {
+                    const uint32_t idx = ((uint32_t)bh * (uint32_t)p.Tq + (uint32_t)qq) * (uint32_t)p.Tk + (uint32_t)key;
+                    const bool keep = p.drop.keep(idx);
+                    pdr = keep ? pv * p.drop.scale : 0.f;
+                    gr = keep ? gr * p.drop.scale : 0.f;
+                }
+                pd[r] = pdr;
+                ds[r] = pv * (gr - da[c]);
+            }
+        }
+        mma_acc_lds<DH>(dvacc, pd, dOs, l31, half);
+        mma_acc_lds<DH>(dkacc, ds, Qs, l31, half);
+    }
+    float* dkg = p.dk + (size_t)b * p.Tk * p.lddk + h * DH;
+    float* dvg = p.dv + (size_t)b * p.Tk * p.lddv + h * DH;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+        const int kk = k0 + row_of(r, half);
+        if (kk < p.Tk) {
+#pragma unroll
+            for (int dt = 0; dt < DH / 32; ++dt) {
+                dkg[(size_t)kk * p.lddk + dt * 32 + l31] = dkacc[dt][r];
+                dvg[(size_t)kk * p.lddv + dt * 32 + l31] = dvacc[dt][r];
+            }
+        }
+    }
+}
+
+static int check_common(const char* what, int B, int H, int Tq, int Tk, int dh) {
+    CAPDEC_REQUIRE(B > 0 && H > 0 && Tq > 0 && Tk > 0, "%s: bad shape B=%d H=%d Tq=%d Tk=%d", what, B, H, Tq, Tk);
+    CAPDEC_REQUIRE(dh == 32 || dh == 64 || dh == 128, "%s: head dim %d not in {32,64,128}", what, dh);
+    CAPDEC_REQUIRE((uint64_t)B * H * Tq * (uint64_t)Tk < (1ull << 32), "%s: B*H*Tq*Tk exceeds 2^32", what);
+    return 0;
+}
+static bool ok_mat(const void* p, int ld, int H, int dh) { return p && aligned16(p) && ld % 4 == 0 && ld >= H * dh; }
+
+}  // namespace capdec
+
+using namespace capdec;
+
+extern "C" int capdec_attn_fwd(const void* q, int ldq, const void* k, int ldk, const void* v, int ldv, void* o, int ldo,
+                               void* lse, int B, int H, int Tq, int Tk, int dh, int causal, float scale, float drop_p,
+                               uint64_t drop_seed, capdec_stream_t stream) {
+    if (int rc = check_common("capdec_attn_fwd", B, H, Tq, Tk, dh)) return rc;
+    CAPDEC_REQUIRE(ok_mat(q, ldq, H, dh) && ok_mat(k, ldk, H, dh) && ok_mat(v, ldv, H, dh) && ok_mat(o, ldo, H, dh),
+                   "capdec_attn_fwd: operands must be non-null, 16-byte aligned, ld %% 4 == 0, ld >= H*dh");
+    AttnParams p;
+    memset(&p, 0, sizeof(p));
+    p.q = (const float*)q; p.k = (const float*)k; p.v = (const float*)v; p.out = (float*)o; p.lse = (float*)lse;
+    p.ldq = ldq; p.ldk = ldk; p.ldv = ldv; p.ldo = ldo;
+    p.B = B; p.H = H; p.Tq = Tq; p.Tk = Tk; p.causal = causal; p.scale = scale;
+    p.drop = make_dropout(drop_p, drop_seed);
+    const dim3 grid(B * H * ((Tq + 31) / 32));
+    hipStream_t st = (hipStream_t)stream;
+    if (dh == 32) hipLaunchKernelGGL(attn_fwd_kernel<32>, grid, dim3(64), 0, st, p);
+    else if (dh == 64) hipLaunchKernelGGL(attn_fwd_kernel<64>, grid, dim3(64), 0, st, p);
+    else hipLaunchKernelGGL(attn_fwd_kernel<128>, grid, dim3(64), 0, st, p);
+    return check_launch("capdec_attn_fwd");
+}
+
+extern "C" int capdec_attn_bwd(const void* q, int ldq, const void* k, int ldk, const void* v, int ldv, const void* o,
+                               int ldo, const void* dout, int lddo, const void* lse, void* delta, void* dq, int lddq,
+                               void* dk, int lddk, void* dv, int lddv, int B, int H, int Tq, int Tk, int dh, int causal,
+                               float scale, float drop_p, uint64_t drop_seed, capdec_stream_t stream) {
+    if (int rc = check_common("capdec_attn_bwd", B, H, Tq, Tk, dh)) return rc;
+    CAPDEC_REQUIRE(ok_mat(q, ldq, H, dh) && ok_mat(k, ldk, H, dh) && ok_mat(v, ldv, H, dh) && ok_mat(o, ldo, H, dh) &&
+                       ok_mat(dout, lddo, H, dh) && ok_mat(dq, lddq, H, dh) && ok_mat(dk, lddk, H, dh) &&
+                       ok_mat(dv, lddv, H, dh) && lse && delta,
+                   "capdec_attn_bwd: operands must be non-null, 16-byte aligned, ld %% 4 == 0, ld >= H*dh");
+    AttnParams p;
+    memset(&p, 0, sizeof(p));
+    p.q = (const float*)q; p.k = (const float*)k; p.v = (const float*)v; p.o = (const float*)o;
+    p.dout = (const float*)dout; p.lse = (float*)lse; p.delta = (float*)delta;
+    p.dq = (float*)dq; p.dk = (float*)dk; p.dv = (float*)dv;
+    p.ldq = ldq; p.ldk = ldk; p.ldv = ldv; p.ldo = ldo; p.lddo = lddo; p.lddq = lddq; p.lddk = lddk; p.lddv = lddv;
+    p.B = B; p.H = H; p.Tq = Tq; p.Tk = Tk; p.causal = causal; p.scale = scale;
+    p.drop = make_dropout(drop_p, drop_seed);
+    hipStream_t st = (hipStream_t)stream;
+    const dim3 gq(B * H * ((Tq + 31) / 32)), gk(B * H * ((Tk + 31) / 32));
+    if (dh == 32) {
+        hipLaunchKernelGGL(attn_bwd_dq_kernel<32>, gq, dim3(64), 0, st, p);
+        hipLaunchKernelGGL(attn_bwd_dkv_kernel<32>, gk, dim3(64), 0, st, p);
+    } else if (dh == 64) {
+        hipLaunchKernelGGL(attn_bwd_dq_kernel<64>, gq, dim3(64), 0, st, p);
+        hipLaunchKernelGGL(attn_bwd_dkv_kernel<64>, gk, dim3(64), 0, st, p);
+    } else {
+        hipLaunchKernelGGL(attn_bwd_dq_kernel<128>, gq, dim3(64), 0, st, p);
+        hipLaunchKernelGGL(attn_bwd_dkv_kernel<128>, gk, dim3(64), 0, st, p);
+    }
+    return check_launch("capdec_attn_bwd");
+}

@@ -1,0 +1,376 @@
+// fp32 GEMM on the gfx950 matrix cores (v_mfma_f32_32x32x2_f32: exact fp32 FMA chains) with a fused
+// bias / GELU / GELU' / dropout / residual epilogue, a fused bias-gradient column sum for
+// weight-gradient products, and deterministic split-K.  See include/capdec.h (capdec_gemm).
+//
+// Block tile BM x BN x 16, 4 waves (2 x 2), each wave owns (BM/2) x (BN/2) as 32x32 accumulators.
+// LDS images (double-buffered, register-prefetched one k-tile ahead):
+//   k-contiguous operand (row-major, reduction index contiguous): [k/4][row][4]  -> one ds_read_b128
+//       per lane yields the operands of four consecutive MFMAs (lane half h owns k = 8j+4h..8j+4h+3);
+//       rows padded by 2 float4 so the 8-lane ds_write_b128 groups and 16-lane ds_read_b128 groups
+//       hit distinct banks.
+//   row-contiguous operand (reduction index is the storage row): [k][row] -> four ds_read_b32.
+#include "common.h"
+
+namespace capdec {
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+
+struct GemmParams {
+    const float* A;
+    const float* B;
+    float* C;
+    int M, N, K, lda, ldb, ldc;
+    const float* bias;
+    const float* addend;
+    float* pre;
+    const float* aux;
+    float* colsum;
+    int ld_addend, act;
+    Dropout drop;
+    int ksplit;       // K elements per z-slice (multiple of 16)
+    float* ws;        // [S][M][N] partial products when gridDim.z > 1
+    float* ws_colsum; // [S][M]
+    int tiles_n;
+};
+
+constexpr int GBK = 16;
+
+__device__ __forceinline__ float epilogue_apply(const GemmParams& p, float v, int m, int n) {
+    if (p.bias) v += p.bias[n];
+    const size_t o = (size_t)m * p.ldc + n;
+    if (p.pre) p.pre[o] = v;
+    if (p.act == CAPDEC_ACT_GELU) v = gelu_erf(v);
+    else if (p.act == CAPDEC_ACT_GELU_BWD) v *= gelu_erf_grad(p.aux[o]);
+    if (p.drop.on()) v = p.drop.apply(v, (uint32_t)m * (uint32_t)p.N + (uint32_t)n);
+    if (p.addend) v += p.addend[(size_t)m * p.ld_addend + n];
+    return v;
+}
+
+template <bool VEC>
+__device__ __forceinline__ float4 load4(const float* ptr, bool ok, int rem) {
+    float4 r = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (!ok || rem <= 0) return r;
+    if (VEC && rem >= 4) return *reinterpret_cast<const float4*>(ptr);
+    r.x = ptr[0];
+    if (rem > 1) r.y = ptr[1];
+    if (rem > 2) r.z = ptr[2];
+    if (rem > 3) r.w = ptr[3];
+    return r;
+}
+
+// AK / BKM: operand is k-contiguous in memory (A stored [M,K]; B stored [N,K]).
+template <int BM, int BN, bool AK, bool BKM, bool VEC>
+__global__ __launch_bounds__(256) void gemm_f32_kernel(GemmParams p) {
+    constexpr int NT = 256;
+    constexpr int TM = BM / 64, TN = BN / 64;  // 32x32 accumulators per wave in each direction
+    constexpr int A_LD = AK ? (BM + 2) * 4 : (BM + 4);  // floats per k-quad (AK) or per k (row-contig)
+    constexpr int B_LD = BKM ? (BN + 2) * 4 : (BN + 4);
+    constexpr int A_SZ = AK ? (GBK / 4) * A_LD : GBK * A_LD;
+    constexpr int B_SZ = BKM ? (GBK / 4) * B_LD : GBK * B_LD;
+    constexpr int A_V4 = BM * GBK / 4 / NT;
+    constexpr int B_V4 = BN * GBK / 4 / NT;
+    static_assert(A_V4 >= 1 && B_V4 >= 1, "tile too small for 256 threads");
+    __shared__ __attribute__((aligned(16))) float smem[2 * (A_SZ + B_SZ)];
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63, wave = tid >> 6;
+    const int l31 = lane & 31, half = lane >> 5;
+    const int wrow = (wave >> 1) * (BM / 2), wcol = (wave & 1) * (BN / 2);
+
+    // XCD-aware tile order: blocks b and b+8 share an XCD (round-robin dispatch), so give each XCD
+    // a contiguous run of tiles (neighbouring tiles share an A row panel in that XCD's L2).
+    const int nwg = gridDim.x;
+    int wg = blockIdx.x;
+    {
+        const int q = nwg >> 3, r = nwg & 7, xcd = wg & 7;
+        wg = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (wg >> 3);
+    }
+    const int m0 = (wg / p.tiles_n) * BM, n0 = (wg % p.tiles_n) * BN;
+    const int kbeg = blockIdx.z * p.ksplit;
+    const int kend = min(p.K, kbeg + p.ksplit);
+    const int nk = (kend - kbeg + GBK - 1) / GBK;
+
+    float4 ra[A_V4], rb[B_V4];
+    auto gload = [&](int k0) {
+#pragma unroll
+        for (int i = 0; i < A_V4; ++i) {
+            const int f = tid + i * NT;
+            if (AK) {
+                const int row = f / (GBK / 4), kq = f % (GBK / 4);
+                const int gm = m0 + row, gk = k0 + kq * 4;
+                ra[i] = load4<VEC>(p.A + (size_t)gm * p.lda + gk, gm < p.M, kend - gk);
+            } else {
+                const int k = f / (BM / 4), rq = f % (BM / 4);
+                const int gk = k0 + k, gm = m0 + rq * 4;
+                ra[i] = load4<VEC>(p.A + (size_t)gk * p.lda + gm, gk < kend, p.M - gm);
+            }
+        }
+#pragma unroll
+        for (int i = 0; i < B_V4; ++i) {
+            const int f = tid + i * NT;
+            if (BKM) {
+                const int row = f / (GBK / 4), kq = f % (GBK / 4);
+                const int gn = n0 + row, gk = k0 + kq * 4;
+                rb[i] = load4<VEC>(p.B + (size_t)gn * p.ldb + gk, gn < p.N, kend - gk);
+            } else {
+                const int k = f / (BN / 4), rq = f % (BN / 4);
+                const int gk = k0 + k, gn = n0 + rq * 4;
+                rb[i] = load4<VEC>(p.B + (size_t)gk * p.ldb + gn, gk < kend, p.N - gn);
+            }
+        }
+    };
+    auto lstore = [&](int buf) {
+        float* As = smem + buf * (A_SZ + B_SZ);
+        float* Bs = As + A_SZ;
+#pragma unroll
+        for (int i = 0; i < A_V4; ++i) {
+            const int f = tid + i * NT;
+            if (AK) {
+                const int row = f / (GBK / 4), kq = f % (GBK / 4);
+                *reinterpret_cast<float4*>(&As[kq * A_LD + row * 4]) = ra[i];
+            } else {
+                const int k = f / (BM / 4), rq = f % (BM / 4);
+                *reinterpret_cast<float4*>(&As[k * A_LD + rq * 4]) = ra[i];
+            }
+        }
+#pragma unroll
+        for (int i = 0; i < B_V4; ++i) {
+            const int f = tid + i * NT;
+            if (BKM) {
+                const int row = f / (GBK / 4), kq = f % (GBK / 4);
+                *reinterpret_cast<float4*>(&Bs[kq * B_LD + row * 4]) = rb[i];
+            } else {
+                const int k = f / (BN / 4), rq = f % (BN / 4);
+                *reinterpret_cast<float4*>(&Bs[k * B_LD + rq * 4]) = rb[i];
+            }
+        }
+    };
+
+    f32x16 acc[TM][TN];
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int j = 0; j < TN; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+    const bool do_colsum = (!AK) && p.colsum != nullptr && (wg % p.tiles_n) == 0;
+    float csum = 0.f;
+
+    if (nk > 0) {
+        gload(kbeg);
+        lstore(0);
+    }
+    __syncthreads();
+    for (int kt = 0; kt < nk; ++kt) {
+        const int buf = kt & 1;
+        if (kt + 1 < nk) gload(kbeg + (kt + 1) * GBK);
+        const float* As = smem + buf * (A_SZ + B_SZ);
+        const float* Bs = As + A_SZ;
+#pragma unroll
+        for (int kb = 0; kb < GBK / 8; ++kb) {
+            float4 af[TM], bf[TN];
+#pragma unroll
+            for (int i = 0; i < TM; ++i) {
+                const int row = wrow + i * 32 + l31;
+                if (AK) {
+                    af[i] = *reinterpret_cast<const float4*>(&As[(kb * 2 + half) * A_LD + row * 4]);
+                } else {
+                    const float* s = &As[(kb * 8 + half * 4) * A_LD + row];
+                    af[i] = make_float4(s[0], s[A_LD], s[2 * A_LD], s[3 * A_LD]);
+                }
+            }
+#pragma unroll
+            for (int j = 0; j < TN; ++j) {
+                const int col = wcol + j * 32 + l31;
+                if (BKM) {
+                    bf[j] = *reinterpret_cast<const float4*>(&Bs[(kb * 2 + half) * B_LD + col * 4]);
+                } else {
+                    const float* s = &Bs[(kb * 8 + half * 4) * B_LD + col];
+                    bf[j] = make_float4(s[0], s[B_LD], s[2 * B_LD], s[3 * B_LD]);
+                }
+            }
+#pragma unroll
+            for (int i = 0; i < TM; ++i)
+#pragma unroll
+                for (int j = 0; j < TN; ++j) {
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[i].x, bf[j].x, acc[i][j], 0, 0, 0);
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[i].y, bf[j].y, acc[i][j], 0, 0, 0);
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[i].z, bf[j].z, acc[i][j], 0, 0, 0);
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[i].w, bf[j].w, acc[i][j], 0, 0, 0);
+                }
+        }
+        if (do_colsum && tid < BM) {
+#pragma unroll
+            for (int k = 0; k < GBK; ++k) csum += As[k * A_LD + tid];
+        }
+        if (kt + 1 < nk) lstore(buf ^ 1);
+        __syncthreads();
+    }
+
+    const bool split = gridDim.z > 1;
+    if (do_colsum && tid < BM && m0 + tid < p.M) {
+        if (split) p.ws_colsum[(size_t)blockIdx.z * p.M + m0 + tid] = csum;
+        else p.colsum[m0 + tid] = csum;
+    }
+    float* wsz = split ? p.ws + (size_t)blockIdx.z * p.M * p.N : nullptr;
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int j = 0; j < TN; ++j) {
+            const int n = n0 + wcol + j * 32 + l31;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int m = m0 + wrow + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * half;
+                if (m < p.M && n < p.N) {
+                    if (split) wsz[(size_t)m * p.N + n] = acc[i][j][r];
+                    else p.C[(size_t)m * p.ldc + n] = epilogue_apply(p, acc[i][j][r], m, n);
+                }
+            }
+        }
+}
+
+__global__ __launch_bounds__(256) void gemm_splitk_reduce_kernel(GemmParams p, int S) {
+    const size_t total = (size_t)p.M * p.N;
+    const size_t stride = (size_t)gridDim.x * blockDim.x;
+    for (size_t e = (size_t)blockIdx.x * blockDim.x + threadIdx.x; e < total; e += stride) {
+        float v = 0.f;
+        for (int z = 0; z < S; ++z) v += p.ws[(size_t)z * total + e];
+        const int m = (int)(e / p.N), n = (int)(e % p.N);
+        p.C[(size_t)m * p.ldc + n] = epilogue_apply(p, v, m, n);
+    }
+    if (p.colsum && blockIdx.x == 0) {
+        for (int m = threadIdx.x; m < p.M; m += blockDim.x) {
+            float v = 0.f;
+            for (int z = 0; z < S; ++z) v += p.ws_colsum[(size_t)z * p.M + m];
+            p.colsum[m] = v;
+        }
+    }
+}
+
+// ---- host side: tile / split-K choice ---------------------------------------------------------
+struct GemmPlan {
+    int bm, bn, split, ksplit;
+};
+
+static inline int cdiv(int a, int b) { return (a + b - 1) / b; }
+
+// MFMA-bound cost model: every SIMD of the 256 CUs runs one wave per resident block; a wave owns
+// (bm/64)*(bn/64) accumulators for K/split reduction steps.  Cost = max work on any SIMD.
+static GemmPlan plan_gemm(int M, int N, int K) {
+    static const int cand[4][2] = {{128, 128}, {128, 64}, {64, 128}, {64, 64}};
+    GemmPlan best{128, 128, 1, K};
+    double best_cost = 1e300;
+    for (int c = 0; c < 4; ++c) {
+        const int bm = cand[c][0], bn = cand[c][1];
+        const int tiles = cdiv(M, bm) * cdiv(N, bn);
+        const double units = (bm / 64) * (bn / 64);
+        for (int split = 1; split <= 32; split *= 2) {
+            int ks = cdiv(cdiv(K, split), GBK) * GBK;
+            if (split > 1 && ks < 128) break;
+            const int s_eff = cdiv(K, ks);
+            const long blocks = (long)tiles * s_eff;
+            const double per_cu = (double)cdiv((int)blocks, 256);
+            // k-loop work + fixed prologue/epilogue per block (in units of one 32x32x16 k-tile)
+            double cost = per_cu * units * (cdiv(ks, GBK) + 6.0);
+            if (s_eff > 1) cost += 0.02 * (double)M * N * s_eff / 65536.0 + 4.0;  // partial write + reduce pass
+            // mild preference for larger tiles (less L2 traffic) on ties
+            cost *= 1.0 + 0.02 * (c);
+            if (cost < best_cost) {
+                best_cost = cost;
+                best = GemmPlan{bm, bn, s_eff, ks};
+            }
+        }
+    }
+    return best;
+}
+
+template <int BM, int BN>
+static void launch_cfg(const GemmParams& p, bool AK, bool BKM, bool vec, dim3 grid, hipStream_t st) {
+#define CAPDEC_LAUNCH(ak, bk, v) hipLaunchKernelGGL((gemm_f32_kernel<BM, BN, ak, bk, v>), grid, dim3(256), 0, st, p)
+    if (vec) {
+        if (AK && BKM) CAPDEC_LAUNCH(true, true, true);
+        else if (AK && !BKM) CAPDEC_LAUNCH(true, false, true);
+        else if (!AK && !BKM) CAPDEC_LAUNCH(false, false, true);
+        else CAPDEC_LAUNCH(false, true, true);
+    } else {
+        if (AK && BKM) CAPDEC_LAUNCH(true, true, false);
+        else if (AK && !BKM) CAPDEC_LAUNCH(true, false, false);
+        else if (!AK && !BKM) CAPDEC_LAUNCH(false, false, false);
+        else CAPDEC_LAUNCH(false, true, false);
+    }
+#undef CAPDEC_LAUNCH
+}
+
+}  // namespace capdec
+
+using namespace capdec;
+
+extern "C" size_t capdec_gemm_workspace_bytes(int M, int N, int K) {
+    if (M <= 0 || N <= 0 || K <= 0) return 0;
+    GemmPlan pl = plan_gemm(M, N, K);
+    if (pl.split <= 1) return 0;
+    return ((size_t)pl.split * M * N + (size_t)pl.split * M) * sizeof(float);
+}
+
+extern "C" int capdec_gemm(int transA, int transB, int M, int N, int K, const void* A, int lda, const void* B,
+                           int ldb, void* C, int ldc, const capdec_epilogue* ep, int dtype, void* workspace,
+                           size_t workspace_bytes, capdec_stream_t stream) {
+    CAPDEC_REQUIRE(dtype == CAPDEC_F32, "capdec_gemm: dtype %d not supported by this entry point", dtype);
+    CAPDEC_REQUIRE(M > 0 && N > 0 && K > 0, "capdec_gemm: bad shape M=%d N=%d K=%d", M, N, K);
+    CAPDEC_REQUIRE(A && B && C, "capdec_gemm: null operand");
+    CAPDEC_REQUIRE(lda >= (transA ? M : K) && ldb >= (transB ? K : N) && ldc >= N,
+                   "capdec_gemm: leading dimension too small (lda=%d ldb=%d ldc=%d)", lda, ldb, ldc);
+    CAPDEC_REQUIRE((uint64_t)M * (uint64_t)N < (1ull << 32), "capdec_gemm: M*N exceeds 2^32 (dropout index)");
+    GemmParams p;
+    memset(&p, 0, sizeof(p));
+    p.A = (const float*)A;
+    p.B = (const float*)B;
+    p.C = (float*)C;
+    p.M = M; p.N = N; p.K = K; p.lda = lda; p.ldb = ldb; p.ldc = ldc;
+    p.drop = make_dropout(0.f, 0);
+    if (ep) {
+        p.bias = (const float*)ep->bias;
+        p.addend = (const float*)ep->addend;
+        p.pre = (float*)ep->pre;
+        p.aux = (const float*)ep->aux;
+        p.colsum = (float*)ep->colsum;
+        p.ld_addend = ep->ld_addend;
+        p.act = ep->act;
+        p.drop = make_dropout(ep->drop_p, ep->drop_seed);
+        CAPDEC_REQUIRE(ep->act != CAPDEC_ACT_GELU_BWD || ep->aux, "capdec_gemm: ACT_GELU_BWD needs aux");
+        CAPDEC_REQUIRE(!ep->colsum || transA, "capdec_gemm: colsum needs transA=1");
+        CAPDEC_REQUIRE(!ep->addend || ep->ld_addend >= N, "capdec_gemm: ld_addend too small");
+        CAPDEC_REQUIRE(ep->drop_p >= 0.f && ep->drop_p < 1.f, "capdec_gemm: drop_p out of range");
+    }
+    GemmPlan pl = plan_gemm(M, N, K);
+    if (pl.split > 1) {
+        const size_t need = ((size_t)pl.split * M * N + (size_t)pl.split * M) * sizeof(float);
+        if (!workspace || workspace_bytes < need) {
+            set_error("capdec_gemm: split-K needs %zu workspace bytes, got %zu", need, workspace_bytes);
+            return CAPDEC_ERR_WORKSPACE;
+        }
+        p.ws = (float*)workspace;
+        p.ws_colsum = p.ws + (size_t)pl.split * M * N;
+    }
+    p.ksplit = pl.ksplit;
+    p.tiles_n = cdiv(N, pl.bn);
+    const bool vec = aligned16(A) && aligned16(B) && (lda % 4 == 0) && (ldb % 4 == 0);
+    const bool AK = !transA, BKM = transB != 0;
+    dim3 grid(cdiv(M, pl.bm) * p.tiles_n, 1, pl.split);
+    hipStream_t st = (hipStream_t)stream;
+    if (pl.bm == 128 && pl.bn == 128) launch_cfg<128, 128>(p, AK, BKM, vec, grid, st);
+    else if (pl.bm == 128 && pl.bn == 64) launch_cfg<128, 64>(p, AK, BKM, vec, grid, st);
+    else if (pl.bm == 64 && pl.bn == 128) launch_cfg<64, 128>(p, AK, BKM, vec, grid, st);
+    else launch_cfg<64, 64>(p, AK, BKM, vec, grid, st);
+    int rc = check_launch("capdec_gemm");
+    if (rc) return rc;
+    if (pl.split > 1) {
+        const size_t total = (size_t)M * N;
+        int blocks = (int)((total + 255) / 256);
+        if (blocks > 2048) blocks = 2048;
+        hipLaunchKernelGGL(gemm_splitk_reduce_kernel, dim3(blocks), dim3(256), 0, st, p, pl.split);
+        rc = check_launch("capdec_gemm(split-K reduce)");
+    }
+    return rc;
+}

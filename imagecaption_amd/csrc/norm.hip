@@ -1,0 +1,235 @@
+// LayerNorm forward / backward (optionally fused with erf-GELU and dropout), one wave per row.
+// HBM-bound: every row is read once into registers (float4 per lane), reduced with wave
+// shuffles, and written once.  Backward accumulates dgamma/dbeta partials in registers across a
+// grid-stride loop over rows and reduces them deterministically (fixed block count, fixed order).
+// See include/capdec.h (capdec_layernorm_fwd / _bwd).
+#include "common.h"
+
+namespace capdec {
+
+constexpr int LN_MAX_BLOCKS = 512;
+
+template <int NV>
+__global__ __launch_bounds__(256) void ln_fwd_kernel(const float* __restrict__ x, const float* __restrict__ gamma,
+                                                      const float* __restrict__ beta, float* __restrict__ y,
+                                                      float* __restrict__ mean_out, float* __restrict__ rstd_out, int M,
+                                                      int d, float eps, int act, Dropout drop) {
+    const int lane = threadIdx.x & 63;
+    const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (row >= M) return;
+    const int nq = d >> 2;
+    const float4* xr = reinterpret_cast<const float4*>(x + (size_t)row * d);
+    float4 v[NV];
+    float s = 0.f;
+#pragma unroll
+    for (int i = 0; i < NV; ++i) {
+        const int q = lane + 64 * i;
+        v[i] = q < nq ? xr[q] : make_float4(0.f, 0.f, 0.f, 0.f);
+        s += (v[i].x + v[i].y) + (v[i].z + v[i].w);
+    }
+    const float mean = wave_sum(s) / (float)d;
+    float ss = 0.f;
+#pragma unroll
+    for (int i = 0; i < NV; ++i) {
+        const int q = lane + 64 * i;
+        if (q < nq) {
+            const float a = v[i].x - mean, b = v[i].y - mean, c = v[i].z - mean, e = v[i].w - mean;
+            ss += (a * a + b * b) + (c * c + e * e);
+        }
+    }
+    const float rstd = rsqrtf(wave_sum(ss) / (float)d + eps);
+    if (lane == 0) {
+        if (mean_out) mean_out[row] = mean;
+        if (rstd_out) rstd_out[row] = rstd;
+    }
+    float4* yr = reinterpret_cast<float4*>(y + (size_t)row * d);
+    const float4* g4 = reinterpret_cast<const float4*>(gamma);
+    const float4* b4 = reinterpret_cast<const float4*>(beta);
+#pragma unroll
+    for (int i = 0; i < NV; ++i) {
+        const int q = lane + 64 * i;
+        if (q < nq) {
+            const float4 g = g4[q], b = b4[q];
+            float o[4] = {(v[i].x - mean) * rstd * g.x + b.x, (v[i].y - mean) * rstd * g.y + b.y,
+                          (v[i].z - mean) * rstd * g.z + b.z, (v[i].w - mean) * rstd * g.w + b.w};
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                if (act == CAPDEC_ACT_GELU) o[j] = gelu_erf(o[j]);
+                if (drop.on()) o[j] = drop.apply(o[j], (uint32_t)row * (uint32_t)d + (uint32_t)(q * 4 + j));
+            }
+            yr[q] = make_float4(o[0], o[1], o[2], o[3]);
+        }
+    }
+}
+
+template <int NV>
+__global__ __launch_bounds__(256) void ln_bwd_kernel(const float* __restrict__ dy, const float* __restrict__ x,
+                                                      const float* __restrict__ gamma, const float* __restrict__ beta,
+                                                      const float* __restrict__ mean_in, const float* __restrict__ rstd_in,
+                                                      float* __restrict__ dx, float* __restrict__ dx_drop,
+                                                      float* __restrict__ part, int M, int d, int act, Dropout drop,
+                                                      Dropout drop2) {
+    __shared__ float red[4][2][NV * 256];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int nq = d >> 2;
+    const float4* g4 = reinterpret_cast<const float4*>(gamma);
+    const float4* b4 = reinterpret_cast<const float4*>(beta);
+    float4 gm[NV], bt[NV];
+    float dg[NV][4], db[NV][4];
+#pragma unroll
+    for (int i = 0; i < NV; ++i) {
+        const int q = lane + 64 * i;
+        gm[i] = q < nq ? g4[q] : make_float4(0.f, 0.f, 0.f, 0.f);
+        bt[i] = (q < nq && act == CAPDEC_ACT_GELU) ? b4[q] : make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
+        for (int j = 0; j < 4; ++j) dg[i][j] = db[i][j] = 0.f;
+    }
+    const float inv_d = 1.0f / (float)d;
+    for (int row = blockIdx.x * 4 + wave; row < M; row += gridDim.x * 4) {
+        const float mean = mean_in[row], rstd = rstd_in[row];
+        const float4* xr = reinterpret_cast<const float4*>(x + (size_t)row * d);
+        const float4* dyr = reinterpret_cast<const float4*>(dy + (size_t)row * d);
+        float xh[NV][4], g[NV][4];
+        float s1 = 0.f, s2 = 0.f;
+#pragma unroll
+        for (int i = 0; i < NV; ++i) {
+            const int q = lane + 64 * i;
+            if (q < nq) {
+                const float4 xv = xr[q], dv = dyr[q];
+                const float xa[4] = {xv.x, xv.y, xv.z, xv.w};
+                float da[4] = {dv.x, dv.y, dv.z, dv.w};
+                const float ga[4] = {gm[i].x, gm[i].y, gm[i].z, gm[i].w};
+                const float ba[4] = {bt[i].x, bt[i].y, bt[i].z, bt[i].w};
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    xh[i][j] = (xa[j] - mean) * rstd;
+                    if (drop.on()) da[j] = drop.apply(da[j], (uint32_t)row * (uint32_t)d + (uint32_t)(q * 4 + j));
+                    if (act == CAPDEC_ACT_GELU) da[j] *= gelu_erf_grad(xh[i][j] * ga[j] + ba[j]);
+                    dg[i][j] += da[j] * xh[i][j];
+                    db[i][j] += da[j];
+                    g[i][j] = da[j] * ga[j];
+                    s1 += g[i][j];
+                    s2 += g[i][j] * xh[i][j];
+                }
+            } else {
+#pragma unroll
+                for (int j = 0; j < 4; ++j) xh[i][j] = g[i][j] = 0.f;
+            }
+        }
+        const float c1 = wave_sum(s1) * inv_d, c2 = wave_sum(s2) * inv_d;
+        float4* dxr = reinterpret_cast<float4*>(dx + (size_t)row * d);
+        float4* dxd = dx_drop ? reinterpret_cast<float4*>(dx_drop + (size_t)row * d) : nullptr;
+#pragma unroll
+        for (int i = 0; i < NV; ++i) {
+            const int q = lane + 64 * i;
+            if (q < nq) {
+                float o[4];
+#pragma unroll
+                for (int j = 0; j < 4; ++j) o[j] = rstd * (g[i][j] - c1 - xh[i][j] * c2);
+                dxr[q] = make_float4(o[0], o[1], o[2], o[3]);
+                if (dxd) {
+#pragma unroll
+                    for (int j = 0; j < 4; ++j)
+                        o[j] = drop2.on() ? drop2.apply(o[j], (uint32_t)row * (uint32_t)d + (uint32_t)(q * 4 + j)) : o[j];
+                    dxd[q] = make_float4(o[0], o[1], o[2], o[3]);
+                }
+            }
+        }
+    }
+    // block reduction of the per-wave partial column sums, then one partial row per block
+#pragma unroll
+    for (int i = 0; i < NV; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            red[wave][0][(lane + 64 * i) * 4 + j] = dg[i][j];
+            red[wave][1][(lane + 64 * i) * 4 + j] = db[i][j];
+        }
+    __syncthreads();
+    for (int c = threadIdx.x; c < d; c += 256) {
+        part[((size_t)blockIdx.x * 2 + 0) * d + c] = (red[0][0][c] + red[1][0][c]) + (red[2][0][c] + red[3][0][c]);
+        part[((size_t)blockIdx.x * 2 + 1) * d + c] = (red[0][1][c] + red[1][1][c]) + (red[2][1][c] + red[3][1][c]);
+    }
+}
+
+__global__ __launch_bounds__(256) void ln_bwd_finalize_kernel(const float* __restrict__ part, float* __restrict__ dgamma,
+                                                               float* __restrict__ dbeta, int nblk, int d) {
+    const int c = blockIdx.x * 256 + threadIdx.x;
+    if (c >= d) return;
+    float a = 0.f, b = 0.f;
+    for (int k = 0; k < nblk; ++k) {
+        a += part[((size_t)k * 2 + 0) * d + c];
+        b += part[((size_t)k * 2 + 1) * d + c];
+    }
+    dgamma[c] = a;
+    dbeta[c] = b;
+}
+
+static int ln_blocks(int M) {
+    int b = (M + 3) / 4;
+    return b > LN_MAX_BLOCKS ? LN_MAX_BLOCKS : b;
+}
+
+}  // namespace capdec
+
+using namespace capdec;
+
+extern "C" size_t capdec_layernorm_bwd_workspace_bytes(int M, int d) {
+    if (M <= 0 || d <= 0) return 0;
+    return (size_t)ln_blocks(M) * 2 * d * sizeof(float);
+}
+
+#define LN_DISPATCH(NVREQ, CALL)           \
+    if ((NVREQ) <= 1) { CALL(1); }         \
+    else if ((NVREQ) <= 2) { CALL(2); }    \
+    else if ((NVREQ) <= 4) { CALL(4); }    \
+    else if ((NVREQ) <= 8) { CALL(8); }    \
+    else { CALL(16); }
+
+extern "C" int capdec_layernorm_fwd(const void* x, const void* gamma, const void* beta, void* y, void* mean, void* rstd,
+                                    int M, int d, float eps, int act, float drop_p, uint64_t drop_seed,
+                                    capdec_stream_t stream) {
+    CAPDEC_REQUIRE(x && gamma && beta && y, "capdec_layernorm_fwd: null pointer");
+    CAPDEC_REQUIRE(M > 0 && d > 0 && d % 4 == 0 && d <= 4096, "capdec_layernorm_fwd: bad shape M=%d d=%d", M, d);
+    CAPDEC_REQUIRE(aligned16(x) && aligned16(y) && aligned16(gamma) && aligned16(beta), "capdec_layernorm_fwd: unaligned");
+    CAPDEC_REQUIRE((uint64_t)M * (uint64_t)d < (1ull << 32), "capdec_layernorm_fwd: M*d exceeds 2^32");
+    const Dropout dr = make_dropout(drop_p, drop_seed);
+    const int nv = (d + 255) / 256;
+    hipStream_t st = (hipStream_t)stream;
+#define CALL(NV)                                                                                                    \
+    hipLaunchKernelGGL((ln_fwd_kernel<NV>), dim3((M + 3) / 4), dim3(256), 0, st, (const float*)x, (const float*)gamma, \
+                       (const float*)beta, (float*)y, (float*)mean, (float*)rstd, M, d, eps, act, dr)
+    LN_DISPATCH(nv, CALL)
+#undef CALL
+    return check_launch("capdec_layernorm_fwd");
+}
+
+extern "C" int capdec_layernorm_bwd(const void* dy, const void* x, const void* gamma, const void* beta, const void* mean,
+                                    const void* rstd, void* dx, void* dx_drop, void* dgamma, void* dbeta, int M, int d,
+                                    int act, float drop_p, uint64_t drop_seed, float drop2_p, uint64_t drop2_seed,
+                                    void* workspace, size_t workspace_bytes, capdec_stream_t stream) {
+    CAPDEC_REQUIRE(dy && x && gamma && beta && mean && rstd && dx && dgamma && dbeta, "capdec_layernorm_bwd: null pointer");
+    CAPDEC_REQUIRE(M > 0 && d > 0 && d % 4 == 0 && d <= 2048, "capdec_layernorm_bwd: bad shape M=%d d=%d", M, d);
+    CAPDEC_REQUIRE(aligned16(x) && aligned16(dy) && aligned16(dx) && aligned16(gamma) && aligned16(beta) &&
+                       (!dx_drop || aligned16(dx_drop)), "capdec_layernorm_bwd: unaligned");
+    CAPDEC_REQUIRE((uint64_t)M * (uint64_t)d < (1ull << 32), "capdec_layernorm_bwd: M*d exceeds 2^32");
+    const int nblk = ln_blocks(M);
+    const size_t need = (size_t)nblk * 2 * d * sizeof(float);
+    if (!workspace || workspace_bytes < need) {
+        set_error("capdec_layernorm_bwd: needs %zu workspace bytes, got %zu", need, workspace_bytes);
+        return CAPDEC_ERR_WORKSPACE;
+    }
+    const Dropout dr = make_dropout(drop_p, drop_seed), dr2 = make_dropout(drop2_p, drop2_seed);
+    const int nv = (d + 255) / 256;
+    hipStream_t st = (hipStream_t)stream;
+#define CALL(NV)                                                                                                     \
+    hipLaunchKernelGGL((ln_bwd_kernel<NV>), dim3(nblk), dim3(256), 0, st, (const float*)dy, (const float*)x,          \
+                       (const float*)gamma, (const float*)beta, (const float*)mean, (const float*)rstd, (float*)dx,   \
+                       (float*)dx_drop, (float*)workspace, M, d, act, dr, dr2)
+    if (nv <= 1) { CALL(1); } else if (nv <= 2) { CALL(2); } else if (nv <= 4) { CALL(4); } else { CALL(8); }
+#undef CALL
+    int rc = check_launch("capdec_layernorm_bwd");
+    if (rc) return rc;
+    hipLaunchKernelGGL(ln_bwd_finalize_kernel, dim3((d + 255) / 256), dim3(256), 0, st, (const float*)workspace,
+                       (float*)dgamma, (float*)dbeta, nblk, d);
+    return check_launch("capdec_layernorm_bwd(finalize)");
+}

@@ -1,0 +1,202 @@
+"""Launch plans of the caption-decoder hot path: which kernel runs on what, forward and backward.
+
+This is the host-side "graph" of the build.  It is a fixed sequence of C-ABI launches per block
+(no tracing compiler): the same functions serve the autograd wrappers of ``functional.py`` (drop-in
+nn.Module path) and the allocation-light trainer / decoder of ``trainer.py`` / ``decode.py`` (which
+may capture them in a hipGraph).
+
+The arithmetic mirrors, block for block, what the reference executes through torch.nn:
+* decoder layer, post-norm:       torch/nn/modules/transformer.py:1143-1199 (as built at ref models.py:53-65)
+* packed in-projection / SDPA:    torch/nn/functional.py:5819-5852, 6386-6390, 6613-6642
+* feature projection, head:       ref models.py:37-44, 68-73
+Parameter names are the reference's state_dict keys.
+"""
+import torch
+
+from . import ops
+from ._capi import ACT_GELU
+
+LAYER_KEYS = ("self_attn.in_proj_weight", "self_attn.in_proj_bias", "self_attn.out_proj.weight",
+              "self_attn.out_proj.bias", "multihead_attn.in_proj_weight", "multihead_attn.in_proj_bias",
+              "multihead_attn.out_proj.weight", "multihead_attn.out_proj.bias", "linear1.weight", "linear1.bias",
+              "linear2.weight", "linear2.bias", "norm1.weight", "norm1.bias", "norm2.weight", "norm2.bias",
+              "norm3.weight", "norm3.bias")
+PROJ_KEYS = ("0.weight", "0.bias", "1.weight", "1.bias", "4.weight", "4.bias", "5.weight", "5.bias")
+HEAD_KEYS = ("0.weight", "0.bias", "3.weight", "3.bias")
+
+_M64 = (1 << 64) - 1
+
+
+def _splitmix64(x):
+    x = (x + 0x9E3779B97F4A7C15) & _M64
+    z = x
+    z = ((z ^ (z >> 30)) * 0xBF58476D1CE4E5B9) & _M64
+    z = ((z ^ (z >> 27)) * 0x94D049BB133111EB) & _M64
+    return z ^ (z >> 31)
+
+
+class DropoutPlan:
+    """Per-call dropout seeds: seed(site) is a 64-bit hash of (base seed, call counter, site id).
+
+    ``p == 0`` (eval mode) disables every site.  Backward re-derives the
+    masks from the same (p, seed) pairs, so nothing but this small object is kept.
+    """
+
+    def __init__(self, p=0.0, base_seed=0, call=0):
+        self.p = float(p)
+        self.key = _splitmix64((int(base_seed) & _M64) ^ _splitmix64(int(call)))
+
+    def seed(self, site):
+        return _splitmix64(self.key ^ ((int(site) * 0xD6E8FEB86659FD93) & _M64))
+
+
+# site ids: layer l uses 16*l + k; blocks outside the stack use the 1000 range
+S_SA_P, S_SA_OUT, S_CA_P, S_CA_OUT, S_FFN_IN, S_FFN_OUT = range(6)
+S_EMBED, S_PROJ, S_HEAD = 1000, 1001, 1002
+
+
+# ---------------------------------------------------------------------------------------------
+# decoder layer
+# ---------------------------------------------------------------------------------------------
+def layer_fwd(P, x, mem, B, T, S, H, causal, dp, l, save):
+    """x [B*T,d], mem [B*S,d] -> [B*T,d].  ``save`` (dict or None) receives what backward needs."""
+    d = x.shape[1]
+    p, sid = dp.p, 16 * l
+    qkv = ops.linear_fwd(x, P["self_attn.in_proj_weight"], P["self_attn.in_proj_bias"])
+    a, lse1 = ops.attn_fwd(qkv[:, :d], qkv[:, d:2 * d], qkv[:, 2 * d:], B, H, T, T, causal, p, dp.seed(sid + S_SA_P),
+                           save_lse=save is not None)
+    s1 = ops.linear_fwd(a, P["self_attn.out_proj.weight"], P["self_attn.out_proj.bias"], drop_p=p,
+                        seed=dp.seed(sid + S_SA_OUT), addend=x)
+    x1, mean1, rstd1 = ops.layernorm_fwd(s1, P["norm1.weight"], P["norm1.bias"], save_stats=save is not None)
+    wc, bc = P["multihead_attn.in_proj_weight"], P["multihead_attn.in_proj_bias"]
+    q = ops.linear_fwd(x1, wc[:d], bc[:d])
+    kv = ops.linear_fwd(mem, wc[d:], bc[d:])
+    c, lse2 = ops.attn_fwd(q, kv[:, :d], kv[:, d:], B, H, T, S, False, p, dp.seed(sid + S_CA_P),
+                           save_lse=save is not None)
+    s2 = ops.linear_fwd(c, P["multihead_attn.out_proj.weight"], P["multihead_attn.out_proj.bias"], drop_p=p,
+                        seed=dp.seed(sid + S_CA_OUT), addend=x1)
+    x2, mean2, rstd2 = ops.layernorm_fwd(s2, P["norm2.weight"], P["norm2.bias"], save_stats=save is not None)
+    u = torch.empty((x.shape[0], P["linear1.weight"].shape[0]), dtype=torch.float32, device=x.device) \
+        if save is not None else None
+    h = ops.linear_fwd(x2, P["linear1.weight"], P["linear1.bias"], act=ACT_GELU, pre=u, drop_p=p,
+                       seed=dp.seed(sid + S_FFN_IN))
+    s3 = ops.linear_fwd(h, P["linear2.weight"], P["linear2.bias"], drop_p=p, seed=dp.seed(sid + S_FFN_OUT), addend=x2)
+    x3, mean3, rstd3 = ops.layernorm_fwd(s3, P["norm3.weight"], P["norm3.bias"], save_stats=save is not None)
+    if save is not None:
+        save.update(x=x, qkv=qkv, a=a, lse1=lse1, s1=s1, mean1=mean1, rstd1=rstd1, x1=x1, q=q, kv=kv, c=c, lse2=lse2,
+                    s2=s2, mean2=mean2, rstd2=rstd2, x2=x2, u=u, h=h, s3=s3, mean3=mean3, rstd3=rstd3)
+    return x3
+
+
+def layer_bwd(P, G, sv, dx3, mem, dmem, B, T, S, H, causal, dp, l):
+    """Backward of layer_fwd.  Writes parameter grads into G[...] (overwrite); returns (dx, dmem)."""
+    d = dx3.shape[1]
+    p, sid = dp.p, 16 * l
+    tr = p > 0.0
+    g3, g3m, _, _ = ops.layernorm_bwd(dx3, sv["s3"], P["norm3.weight"], P["norm3.bias"], sv["mean3"], sv["rstd3"],
+                                      drop2_p=p, seed2=dp.seed(sid + S_FFN_OUT), want_dx_drop=tr,
+                                      dgamma=G["norm3.weight"], dbeta=G["norm3.bias"])
+    g3m = g3m if tr else g3
+    ops.linear_wgrad(g3m, sv["h"], dw=G["linear2.weight"], db=G["linear2.bias"])
+    du = ops.linear_dgrad(g3m, P["linear2.weight"], gelu_pre=sv["u"], drop_p=p, seed=dp.seed(sid + S_FFN_IN))
+    ops.linear_wgrad(du, sv["x2"], dw=G["linear1.weight"], db=G["linear1.bias"])
+    dx2 = ops.linear_dgrad(du, P["linear1.weight"], addend=g3)
+    g2, g2m, _, _ = ops.layernorm_bwd(dx2, sv["s2"], P["norm2.weight"], P["norm2.bias"], sv["mean2"], sv["rstd2"],
+                                      drop2_p=p, seed2=dp.seed(sid + S_CA_OUT), want_dx_drop=tr,
+                                      dgamma=G["norm2.weight"], dbeta=G["norm2.bias"])
+    g2m = g2m if tr else g2
+    ops.linear_wgrad(g2m, sv["c"], dw=G["multihead_attn.out_proj.weight"], db=G["multihead_attn.out_proj.bias"])
+    dc = ops.linear_dgrad(g2m, P["multihead_attn.out_proj.weight"])
+    kv = sv["kv"]
+    dkv = torch.empty_like(kv)
+    dq, _, _ = ops.attn_bwd(sv["q"], kv[:, :d], kv[:, d:], sv["c"], dc, sv["lse2"], B, H, T, S, False, p,
+                            dp.seed(sid + S_CA_P), dk=dkv[:, :d], dv=dkv[:, d:])
+    wc = P["multihead_attn.in_proj_weight"]
+    gw, gb = G["multihead_attn.in_proj_weight"], G["multihead_attn.in_proj_bias"]
+    ops.linear_wgrad(dq, sv["x1"], dw=gw[:d], db=gb[:d])
+    ops.linear_wgrad(dkv, mem, dw=gw[d:], db=gb[d:])
+    dmem = ops.linear_dgrad(dkv, wc[d:], addend=dmem)
+    dx1 = ops.linear_dgrad(dq, wc[:d], addend=g2)
+    g1, g1m, _, _ = ops.layernorm_bwd(dx1, sv["s1"], P["norm1.weight"], P["norm1.bias"], sv["mean1"], sv["rstd1"],
+                                      drop2_p=p, seed2=dp.seed(sid + S_SA_OUT), want_dx_drop=tr,
+                                      dgamma=G["norm1.weight"], dbeta=G["norm1.bias"])
+    g1m = g1m if tr else g1
+    ops.linear_wgrad(g1m, sv["a"], dw=G["self_attn.out_proj.weight"], db=G["self_attn.out_proj.bias"])
+    da = ops.linear_dgrad(g1m, P["self_attn.out_proj.weight"])
+    qkv = sv["qkv"]
+    dqkv = torch.empty_like(qkv)
+    ops.attn_bwd(qkv[:, :d], qkv[:, d:2 * d], qkv[:, 2 * d:], sv["a"], da, sv["lse1"], B, H, T, T, causal, p,
+                 dp.seed(sid + S_SA_P), dq=dqkv[:, :d], dk=dqkv[:, d:2 * d], dv=dqkv[:, 2 * d:])
+    ops.linear_wgrad(dqkv, sv["x"], dw=G["self_attn.in_proj_weight"], db=G["self_attn.in_proj_bias"])
+    dx = ops.linear_dgrad(dqkv, P["self_attn.in_proj_weight"], addend=g1)
+    return dx, dmem
+
+
+# ---------------------------------------------------------------------------------------------
+# decoder stack (+ final norm), feature projection, output head
+# ---------------------------------------------------------------------------------------------
+def stack_fwd(layers, norm_w, norm_b, x, mem, B, T, S, H, causal, dp, save):
+    saves = [] if save is not None else None
+    for l, P in enumerate(layers):
+        sv = {} if save is not None else None
+        x = layer_fwd(P, x, mem, B, T, S, H, causal, dp, l, sv)
+        if saves is not None:
+            saves.append(sv)
+    y, mean, rstd = ops.layernorm_fwd(x, norm_w, norm_b, save_stats=save is not None)
+    if save is not None:
+        save.update(layers=saves, xl=x, mean=mean, rstd=rstd)
+    return y
+
+
+def stack_bwd(layers, grads, norm_w, norm_b, g_norm_w, g_norm_b, sv, dy, mem, B, T, S, H, causal, dp,
+              after_layer=None):
+    """``after_layer(l)`` is called once layer l's parameter grads are enqueued (bucketed all-reduce hook)."""
+    dx, _, _, _ = ops.layernorm_bwd(dy, sv["xl"], norm_w, norm_b, sv["mean"], sv["rstd"], dgamma=g_norm_w,
+                                    dbeta=g_norm_b)
+    dmem = None
+    for l in range(len(layers) - 1, -1, -1):
+        dx, dmem = layer_bwd(layers[l], grads[l], sv["layers"][l], dx, mem, dmem, B, T, S, H, causal, dp, l)
+        if after_layer is not None:
+            after_layer(l)
+    return dx, dmem
+
+
+def proj_fwd(P, f, dp, save):
+    """feature_projection (ref models.py:37-44): Linear, LN, GELU, Dropout, Linear, LN on f [R,Din]."""
+    h0 = ops.linear_fwd(f, P["0.weight"], P["0.bias"])
+    h1, mean1, rstd1 = ops.layernorm_fwd(h0, P["1.weight"], P["1.bias"], act=ACT_GELU, drop_p=dp.p,
+                                         seed=dp.seed(S_PROJ), save_stats=save is not None)
+    h2 = ops.linear_fwd(h1, P["4.weight"], P["4.bias"])
+    mem, mean5, rstd5 = ops.layernorm_fwd(h2, P["5.weight"], P["5.bias"], save_stats=save is not None)
+    if save is not None:
+        save.update(f=f, h0=h0, mean1=mean1, rstd1=rstd1, h1=h1, h2=h2, mean5=mean5, rstd5=rstd5)
+    return mem
+
+
+def proj_bwd(P, G, sv, dmem, dp, want_df=False):
+    g5, _, _, _ = ops.layernorm_bwd(dmem, sv["h2"], P["5.weight"], P["5.bias"], sv["mean5"], sv["rstd5"],
+                                    dgamma=G["5.weight"], dbeta=G["5.bias"])
+    ops.linear_wgrad(g5, sv["h1"], dw=G["4.weight"], db=G["4.bias"])
+    dh1 = ops.linear_dgrad(g5, P["4.weight"])
+    g1, _, _, _ = ops.layernorm_bwd(dh1, sv["h0"], P["1.weight"], P["1.bias"], sv["mean1"], sv["rstd1"], act=ACT_GELU,
+                                    drop_p=dp.p, seed=dp.seed(S_PROJ), dgamma=G["1.weight"], dbeta=G["1.bias"])
+    ops.linear_wgrad(g1, sv["f"], dw=G["0.weight"], db=G["0.bias"])
+    return ops.linear_dgrad(g1, P["0.weight"]) if want_df else None
+
+
+def head_fwd(P, x, dp, save, logits_out=None):
+    """output_layer (ref models.py:68-73): Linear, GELU, Dropout, Linear on x [M,d] -> logits [M,V]."""
+    u = torch.empty((x.shape[0], P["0.weight"].shape[0]), dtype=torch.float32, device=x.device) \
+        if save is not None else None
+    h = ops.linear_fwd(x, P["0.weight"], P["0.bias"], act=ACT_GELU, pre=u, drop_p=dp.p, seed=dp.seed(S_HEAD))
+    logits = ops.linear_fwd(h, P["3.weight"], P["3.bias"], out=logits_out)
+    if save is not None:
+        save.update(x=x, u=u, h=h)
+    return logits
+
+
+def head_bwd(P, G, sv, dlogits, dp):
+    ops.linear_wgrad(dlogits, sv["h"], dw=G["3.weight"], db=G["3.bias"])
+    du = ops.linear_dgrad(dlogits, P["3.weight"], gelu_pre=sv["u"], drop_p=dp.p, seed=dp.seed(S_HEAD))
+    ops.linear_wgrad(du, sv["x"], dw=G["0.weight"], db=G["0.bias"])
+    return ops.linear_dgrad(du, P["0.weight"])

@@ -1,0 +1,245 @@
+"""Raw (non-autograd) tensor-level wrappers over the C ABI.  Plumbing only: shapes, strides, pointers.
+
+Every function enqueues hand-written gfx950 kernels on torch's current HIP stream.  2-D operands
+may be row-strided views (``stride(1) == 1``), e.g. the q / k / v slices of a packed projection.
+"""
+import ctypes as C
+import math
+
+import torch
+
+from . import _capi
+from ._capi import ACT_GELU, ACT_GELU_BWD, ACT_NONE, F32, check, lib, ptr, stream
+
+__all__ = ["gemm", "linear_fwd", "linear_dgrad", "linear_wgrad", "layernorm_fwd", "layernorm_bwd", "embed_fwd",
+           "embed_bwd", "attn_fwd", "attn_bwd", "softmax_ce", "reduce_sum", "sumsq", "adamw", "clip_scale", "pe_add",
+           "act_dropout_bwd"]
+
+
+def _req(t, name, dtype=torch.float32):
+    if not t.is_cuda:
+        raise _capi.CapdecError(f"{name}: tensor is on {t.device}; the capdec ops run on the GPU only (no CPU fallback)")
+    if t.dtype != dtype:
+        raise _capi.CapdecError(f"{name}: dtype {t.dtype}, expected {dtype}")
+    return t
+
+
+def _mat(t, name):
+    _req(t, name)
+    if t.dim() != 2 or t.stride(1) != 1:
+        raise _capi.CapdecError(f"{name}: need a 2-D tensor with unit column stride, got {tuple(t.shape)} / {t.stride()}")
+    return t
+
+
+def gemm(a, b, trans_a, trans_b, out=None, bias=None, addend=None, pre=None, aux=None, colsum=None, act=ACT_NONE,
+         drop_p=0.0, seed=0):
+    """out[M,N] = epilogue(op(a) @ op(b)); see capdec_gemm in include/capdec.h."""
+    _mat(a, "gemm.a"), _mat(b, "gemm.b")
+    M, K = (a.shape[1], a.shape[0]) if trans_a else (a.shape[0], a.shape[1])
+    Kb, N = (b.shape[1], b.shape[0]) if trans_b else (b.shape[0], b.shape[1])
+    if K != Kb:
+        raise _capi.CapdecError(f"gemm: inner dimensions differ ({K} vs {Kb})")
+    if out is None:
+        out = torch.empty((M, N), dtype=torch.float32, device=a.device)
+    _mat(out, "gemm.out")
+    if tuple(out.shape) != (M, N):
+        raise _capi.CapdecError(f"gemm: out is {tuple(out.shape)}, expected {(M, N)}")
+    ep = _capi.Epilogue()
+    ep.bias, ep.addend, ep.pre, ep.aux, ep.colsum = ptr(bias), ptr(addend), ptr(pre), ptr(aux), ptr(colsum)
+    ep.ld_addend = addend.stride(0) if addend is not None else 0
+    for t, n in ((pre, "pre"), (aux, "aux")):
+        if t is not None and (t.stride(0) != out.stride(0) or tuple(t.shape) != (M, N)):
+            raise _capi.CapdecError(f"gemm: {n} must have the shape and row stride of out")
+    if bias is not None and bias.numel() != N:
+        raise _capi.CapdecError("gemm: bias must have N elements")
+    if addend is not None and tuple(addend.shape) != (M, N):
+        raise _capi.CapdecError("gemm: addend must be [M,N]")
+    if colsum is not None and colsum.numel() != M:
+        raise _capi.CapdecError("gemm: colsum must have M elements")
+    ep.act, ep.drop_p, ep.drop_seed = act, float(drop_p), int(seed) & 0xFFFFFFFFFFFFFFFF
+    l = lib()
+    need = l.capdec_gemm_workspace_bytes(M, N, K)
+    ws = _capi.workspace(need, a.device) if need else None
+    check(l.capdec_gemm(int(trans_a), int(trans_b), M, N, K, ptr(a), a.stride(0), ptr(b), b.stride(0), ptr(out),
+                        out.stride(0), C.byref(ep), F32, ptr(ws), ws.numel() if ws is not None else 0, stream()),
+          "capdec_gemm")
+    return out
+
+
+def linear_fwd(x, w, bias=None, out=None, act=ACT_NONE, pre=None, drop_p=0.0, seed=0, addend=None):
+    """y = addend + dropout(act(x @ w.T + bias)); x [M,K], w [N,K]."""
+    return gemm(x, w, False, True, out=out, bias=bias, addend=addend, pre=pre, act=act, drop_p=drop_p, seed=seed)
+
+
+def linear_dgrad(dy, w, out=None, addend=None, gelu_pre=None, drop_p=0.0, seed=0):
+    """dx = addend + dropout_mask * gelu'(gelu_pre) * (dy @ w); dy [M,N], w [N,K]."""
+    act = ACT_GELU_BWD if gelu_pre is not None else ACT_NONE
+    return gemm(dy, w, False, False, out=out, addend=addend, aux=gelu_pre, act=act, drop_p=drop_p, seed=seed)
+
+
+def linear_wgrad(dy, x, dw=None, db=None):
+    """dw[N,K] = dy.T @ x, db[N] = column sums of dy (fused into the same kernel)."""
+    return gemm(dy, x, True, False, out=dw, colsum=db)
+
+
+def layernorm_fwd(x, gamma, beta, eps=1e-5, act=ACT_NONE, drop_p=0.0, seed=0, save_stats=True, out=None):
+    _mat(x, "layernorm.x")
+    if not x.is_contiguous():
+        raise _capi.CapdecError("layernorm_fwd: x must be contiguous")
+    M, d = x.shape
+    y = torch.empty_like(x) if out is None else out
+    mean = torch.empty(M, dtype=torch.float32, device=x.device) if save_stats else None
+    rstd = torch.empty(M, dtype=torch.float32, device=x.device) if save_stats else None
+    check(lib().capdec_layernorm_fwd(ptr(x), ptr(gamma), ptr(beta), ptr(y), ptr(mean), ptr(rstd), M, d, float(eps), act,
+                                     float(drop_p), int(seed), stream()), "capdec_layernorm_fwd")
+    return y, mean, rstd
+
+
+def layernorm_bwd(dy, x, gamma, beta, mean, rstd, act=ACT_NONE, drop_p=0.0, seed=0, drop2_p=0.0, seed2=0,
+                  want_dx_drop=False, dgamma=None, dbeta=None):
+    _mat(x, "layernorm_bwd.x"), _mat(dy, "layernorm_bwd.dy")
+    if not (x.is_contiguous() and dy.is_contiguous()):
+        raise _capi.CapdecError("layernorm_bwd: x and dy must be contiguous")
+    M, d = x.shape
+    dx = torch.empty_like(x)
+    dx_drop = torch.empty_like(x) if want_dx_drop else None
+    if dgamma is None:
+        dgamma = torch.empty(d, dtype=torch.float32, device=x.device)
+    if dbeta is None:
+        dbeta = torch.empty(d, dtype=torch.float32, device=x.device)
+    l = lib()
+    need = l.capdec_layernorm_bwd_workspace_bytes(M, d)
+    ws = _capi.workspace(need, x.device)
+    check(l.capdec_layernorm_bwd(ptr(dy), ptr(x), ptr(gamma), ptr(beta), ptr(mean), ptr(rstd), ptr(dx), ptr(dx_drop),
+                                 ptr(dgamma), ptr(dbeta), M, d, act, float(drop_p), int(seed), float(drop2_p),
+                                 int(seed2), ptr(ws), ws.numel(), stream()), "capdec_layernorm_bwd")
+    return dx, dx_drop, dgamma, dbeta
+
+
+def embed_fwd(ids, E, pe, t0=0, drop_p=0.0, seed=0):
+    """out[b,t,:] = dropout(E[ids[b,t]] + pe[t0+t]); ids int64 [B,T], E [V,d], pe [>=t0+T, d] contiguous."""
+    _req(ids, "embed.ids", torch.int64)
+    ids = ids.contiguous()
+    B, T = ids.shape
+    V, d = E.shape
+    if pe.shape[0] < t0 + T or pe.shape[-1] != d or not pe.is_contiguous():
+        raise _capi.CapdecError("embed_fwd: positional table too short / wrong width / not contiguous")
+    out = torch.empty((B, T, d), dtype=torch.float32, device=E.device)
+    check(lib().capdec_embed_fwd(ptr(ids), ptr(_req(E, "embed.E")), ptr(_req(pe, "embed.pe")), ptr(out), B, T, d, V,
+                                 int(t0), float(drop_p), int(seed), stream()), "capdec_embed_fwd")
+    return out
+
+
+def embed_bwd(ids, dout, V, drop_p=0.0, seed=0, dE=None):
+    ids = ids.contiguous()
+    B, T = ids.shape
+    d = dout.shape[-1]
+    dout = dout.contiguous()
+    if dE is None:
+        dE = torch.empty((V, d), dtype=torch.float32, device=dout.device)
+    l = lib()
+    ws = _capi.workspace(l.capdec_embed_bwd_workspace_bytes(V), dout.device)
+    check(l.capdec_embed_bwd(ptr(ids), ptr(_req(dout, "embed_bwd.dout")), ptr(dE), B, T, d, V, float(drop_p), int(seed),
+                             ptr(ws), ws.numel(), stream()), "capdec_embed_bwd")
+    return dE
+
+
+def attn_fwd(q, k, v, B, H, Tq, Tk, causal, drop_p=0.0, seed=0, out=None, save_lse=True):
+    """q [B*Tq, >=H*dh] / k, v [B*Tk, ...] row-strided 2-D views; returns o [B*Tq, H*dh], lse [B,H,Tq]."""
+    _mat(q, "attn.q"), _mat(k, "attn.k"), _mat(v, "attn.v")
+    D = q.shape[1]
+    dh = D // H
+    o = torch.empty((B * Tq, D), dtype=torch.float32, device=q.device) if out is None else out
+    lse = torch.empty((B, H, Tq), dtype=torch.float32, device=q.device) if save_lse else None
+    check(lib().capdec_attn_fwd(ptr(q), q.stride(0), ptr(k), k.stride(0), ptr(v), v.stride(0), ptr(o), o.stride(0),
+                                ptr(lse), B, H, Tq, Tk, dh, int(causal), 1.0 / math.sqrt(dh), float(drop_p), int(seed),
+                                stream()), "capdec_attn_fwd")
+    return o, lse
+
+
+def attn_bwd(q, k, v, o, do, lse, B, H, Tq, Tk, causal, drop_p=0.0, seed=0, dq=None, dk=None, dv=None):
+    D = q.shape[1]
+    dh = D // H
+    _mat(do, "attn_bwd.do")
+    dq = torch.empty((B * Tq, D), dtype=torch.float32, device=q.device) if dq is None else dq
+    dk = torch.empty((B * Tk, D), dtype=torch.float32, device=q.device) if dk is None else dk
+    dv = torch.empty((B * Tk, D), dtype=torch.float32, device=q.device) if dv is None else dv
+    delta = torch.empty((B, H, Tq), dtype=torch.float32, device=q.device)
+    check(lib().capdec_attn_bwd(ptr(q), q.stride(0), ptr(k), k.stride(0), ptr(v), v.stride(0), ptr(o), o.stride(0),
+                                ptr(do), do.stride(0), ptr(lse), ptr(delta), ptr(dq), dq.stride(0), ptr(dk),
+                                dk.stride(0), ptr(dv), dv.stride(0), B, H, Tq, Tk, dh, int(causal),
+                                1.0 / math.sqrt(dh), float(drop_p), int(seed), stream()), "capdec_attn_bwd")
+    return dq, dk, dv
+
+
+def softmax_ce(logits, targets, eps=0.1, grad_scale=None, want_grad=True, in_place=False):
+    """Label-smoothed CE rows + (optionally) dlogits; logits [M,V], targets int64 [M]."""
+    _mat(logits, "softmax_ce.logits")
+    _req(targets, "softmax_ce.targets", torch.int64)
+    M, V = logits.shape
+    loss_rows = torch.empty(M, dtype=torch.float32, device=logits.device)
+    dl = None
+    if want_grad:
+        dl = logits if in_place else torch.empty((M, V), dtype=torch.float32, device=logits.device)
+    gs = 1.0 / M if grad_scale is None else grad_scale
+    check(lib().capdec_softmax_ce(ptr(logits), logits.stride(0), ptr(targets.contiguous()), ptr(loss_rows), ptr(dl),
+                                  dl.stride(0) if dl is not None else 0, M, V, float(eps), float(gs), stream()),
+          "capdec_softmax_ce")
+    return loss_rows, dl
+
+
+def _reduce(fn, x, *extra):
+    out = torch.empty(1, dtype=torch.float32, device=x.device)
+    l = lib()
+    ws = _capi.workspace(l.capdec_reduce_workspace_bytes(), x.device)
+    return out, ws
+
+
+def reduce_sum(x, scale=1.0):
+    x = _req(x, "sum.x").contiguous()
+    out = torch.empty(1, dtype=torch.float32, device=x.device)
+    l = lib()
+    ws = _capi.workspace(l.capdec_reduce_workspace_bytes(), x.device)
+    check(l.capdec_sum(ptr(x), x.numel(), float(scale), ptr(out), ptr(ws), ws.numel(), stream()), "capdec_sum")
+    return out
+
+
+def sumsq(g, out=None):
+    if not g.is_contiguous():
+        raise _capi.CapdecError("sumsq: tensor must be contiguous")
+    out = torch.empty(1, dtype=torch.float32, device=g.device) if out is None else out
+    l = lib()
+    ws = _capi.workspace(l.capdec_reduce_workspace_bytes(), g.device)
+    check(l.capdec_sumsq(ptr(_req(g, "sumsq.g")), g.numel(), ptr(out), ptr(ws), ws.numel(), stream()), "capdec_sumsq")
+    return out
+
+
+def clip_scale(g, gnorm_sq, max_norm):
+    check(lib().capdec_clip_scale(ptr(g), g.numel(), ptr(gnorm_sq), float(max_norm), stream()), "capdec_clip_scale")
+
+
+def adamw(p, g, m, v, step, lr=1e-3, betas=(0.9, 0.999), eps=1e-8, weight_decay=0.01, gnorm_sq=None, max_norm=1.0):
+    for t in (p, g, m, v):
+        if not t.is_contiguous() or t.numel() != p.numel():
+            raise _capi.CapdecError("adamw: flat contiguous blocks of equal size required")
+    check(lib().capdec_adamw(ptr(p), ptr(g), ptr(m), ptr(v), p.numel(), float(lr), float(betas[0]), float(betas[1]),
+                             float(eps), float(weight_decay), int(step), ptr(gnorm_sq), float(max_norm), stream()),
+          "capdec_adamw")
+
+
+def pe_add(x, pe, div, mod, t0=0, drop_p=0.0, seed=0):
+    x = _req(x, "pe_add.x").contiguous()
+    d = x.shape[-1]
+    R = x.numel() // d
+    out = torch.empty_like(x)
+    check(lib().capdec_pe_add(ptr(x), ptr(pe), ptr(out), R, d, int(div), int(mod), int(t0), float(drop_p), int(seed),
+                              stream()), "capdec_pe_add")
+    return out
+
+
+def act_dropout_bwd(dy, pre=None, drop_p=0.0, seed=0):
+    dy = _req(dy, "act_dropout_bwd.dy").contiguous()
+    out = torch.empty_like(dy)
+    check(lib().capdec_act_dropout_bwd(ptr(dy), ptr(pre), ptr(out), dy.numel(), float(drop_p), int(seed), stream()),
+          "capdec_act_dropout_bwd")
+    return out

@@ -1,0 +1,158 @@
+/* capdec.h -- C ABI of libcapdec.so: the MI355X (gfx950) caption-decoder hot path.
+ *
+ * The reference (EricMoin/ImageCaption) has NO native / FFI interface: its hot path is Python on
+ * torch.nn.  This header is therefore the boundary the build defines
+ * underneath the reference's nn.Module surface; each entry point cites the reference-side
+ * computation it replaces ("ref:" paths are relative to /root/reference, "torch/" means the
+ * installed torch package, which is where the reference's arithmetic lives).
+ *
+ * Conventions
+ *   - every pointer is a BORROWED DEVICE pointer; nothing is allocated, freed or synchronised
+ *     across this ABI; scratch space is passed in as (workspace, workspace_bytes);
+ *   - all matrices are row-major; "ld*" are row strides in ELEMENTS;
+ *   - every call enqueues work on `stream` (a hipStream_t; NULL = the default stream) and returns
+ *     0 (CAPDEC_OK) or a negative error code; capdec_last_error() describes the last failure of
+ *     the calling thread;
+ *   - dtype is CAPDEC_F32 unless an entry point says otherwise;
+ *   - dropout is a counter-based mask keep(i) = hash(i, seed) >= p*2^32 that forward and backward
+ *     regenerate from (seed, element index); p == 0 disables it (eval mode).
+ */
+#ifndef CAPDEC_H_
+#define CAPDEC_H_
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef void* capdec_stream_t; /* hipStream_t */
+
+enum { CAPDEC_OK = 0, CAPDEC_ERR_ARG = -1, CAPDEC_ERR_LAUNCH = -2, CAPDEC_ERR_UNSUPPORTED = -3, CAPDEC_ERR_WORKSPACE = -4 };
+enum { CAPDEC_F32 = 0, CAPDEC_BF16 = 1 };
+enum { CAPDEC_ACT_NONE = 0, CAPDEC_ACT_GELU = 1, CAPDEC_ACT_GELU_BWD = 2 };
+
+int capdec_abi_version(void);
+const char* capdec_last_error(void);
+
+/* ---- GEMM with fused epilogue ---------------------------------------------------------------
+ * C[M,N] = epilogue( opA(A)[M,K] * opB(B)[K,N] ),  opX = X or X^T (row-major storage).
+ *   transA = 0: A stored [M,K] (lda >= K);  transA = 1: A stored [K,M] (lda >= M)
+ *   transB = 0: B stored [K,N] (ldb >= N);  transB = 1: B stored [N,K] (ldb >= K)
+ * epilogue, per element (m,n), in this order:
+ *   v = acc + bias[n]; if (pre) pre[m,n] = v; GELU: v = gelu_erf(v); GELU_BWD: v *= gelu_erf'(aux[m,n]);
+ *   dropout: v = keep(m*N+n) ? v/(1-p) : 0; v += addend[m,n]; C[m,n] = v.
+ * colsum (transA = 1 only): colsum[m] = sum_k opA(A)[m,k]  (the bias gradient of a weight-gradient GEMM).
+ * Replaces: torch/nn/functional.py linear() as called from ref models.py:37-44, 68-73 and
+ * torch/nn/modules/transformer.py:1158-1199 (in/out projections, FFN), plus their autograd
+ * backward (addmm / mm), bias+GELU+dropout+residual fused instead of separate passes.
+ * F32 uses v_mfma_f32_32x32x2_f32 (exact fp32 FMA chains).
+ */
+typedef struct capdec_epilogue {
+    const void* bias;   /* [N] or NULL */
+    const void* addend; /* [M,N], row stride ld_addend, or NULL */
+    void* pre;          /* [M,N], row stride ldc, or NULL */
+    const void* aux;    /* [M,N], row stride ldc; required for ACT_GELU_BWD */
+    void* colsum;       /* [M] or NULL (transA = 1 only) */
+    int ld_addend;
+    int act;
+    float drop_p;
+    uint64_t drop_seed;
+} capdec_epilogue;
+
+size_t capdec_gemm_workspace_bytes(int M, int N, int K);
+int capdec_gemm(int transA, int transB, int M, int N, int K, const void* A, int lda, const void* B, int ldb,
+                void* C, int ldc, const capdec_epilogue* ep, int dtype, void* workspace, size_t workspace_bytes,
+                capdec_stream_t stream);
+
+/* ---- LayerNorm (+ optional GELU + dropout) ----------------------------------------------------
+ * fwd: y = dropout(act(LN(x))), LN eps as given; mean/rstd [M] saved for backward (may be NULL).
+ * bwd: dx = LN'(dy_eff), dy_eff = dy * keep/(1-p) * act'(LN(x)); dgamma/dbeta [d] OVERWRITTEN.
+ *      If dx_drop != NULL also writes dx_drop[i] = keep2(i) ? dx[i]/(1-p2) : 0 with (p2, seed2): the
+ *      gradient entering the dropout that fed this norm's residual branch
+ *      (torch/nn/modules/transformer.py:1144-1153 dropout1/2/3).
+ * Replaces nn.LayerNorm at ref models.py:39, 43, 64 and torch/nn/modules/transformer.py:1076-1078.
+ * d must be a multiple of 4 and <= 2048.
+ */
+size_t capdec_layernorm_bwd_workspace_bytes(int M, int d);
+int capdec_layernorm_fwd(const void* x, const void* gamma, const void* beta, void* y, void* mean, void* rstd,
+                         int M, int d, float eps, int act, float drop_p, uint64_t drop_seed, capdec_stream_t stream);
+int capdec_layernorm_bwd(const void* dy, const void* x, const void* gamma, const void* beta, const void* mean,
+                         const void* rstd, void* dx, void* dx_drop, void* dgamma, void* dbeta, int M, int d,
+                         int act, float drop_p, uint64_t drop_seed, float drop2_p, uint64_t drop2_seed,
+                         void* workspace, size_t workspace_bytes, capdec_stream_t stream);
+
+/* ---- token embedding + sinusoidal positions -----------------------------------------------------
+ * fwd: out[b,t,:] = dropout(E[ids[b,t],:] + pe[t0+t,:]);  ids int64 [B,T]; pe [>=t0+T, d].
+ * bwd: dE[v,:] = sum_{(b,t): ids=v} keep/(1-p) * dout[b,t,:]   (dE fully OVERWRITTEN, deterministic order).
+ * Replaces ref models.py:109-114 (Embedding, transpose, PositionalEncoding.forward models.py:17-19).
+ */
+int capdec_embed_fwd(const int64_t* ids, const void* E, const void* pe, void* out, int B, int T, int d, int V,
+                     int t0, float drop_p, uint64_t drop_seed, capdec_stream_t stream);
+size_t capdec_embed_bwd_workspace_bytes(int V);
+int capdec_embed_bwd(const int64_t* ids, const void* dout, void* dE, int B, int T, int d, int V, float drop_p,
+                     uint64_t drop_seed, void* workspace, size_t workspace_bytes, capdec_stream_t stream);
+
+/* ---- fused attention (scores, softmax, context) --------------------------------------------------
+ * o[b,tq,h,:] = sum_tk dropout(softmax_tk(scale * q[b,tq,h,:].k[b,tk,h,:] + causal)) v[b,tk,h,:]
+ * Element (b,t,h,j) of q/k/v/o lives at ptr[(b*T + t)*ld + h*dh + j]: pass slices of the packed
+ * projection buffers directly.  lse [B,H,Tq] = log-sum-exp of the scaled scores (saved for bwd).
+ * causal: key tk is visible to query tq iff tk <= tq + (Tk - Tq).  dh in {32, 64, 128}.
+ * bwd: dq, dk, dv from do, recomputing probabilities from lse (flash-style, no [Tq,Tk] tensor);
+ *      delta [B,H,Tq] is scratch it fills (rowsum(do*o)).
+ * Replaces torch/nn/functional.py:6386-6390, 6613-6631 (scaled_dot_product_attention inside
+ * multi_head_attention_forward) for both the causal self-attention and the cross-attention over
+ * the image memory (torch/nn/modules/transformer.py:1158-1194).
+ */
+int capdec_attn_fwd(const void* q, int ldq, const void* k, int ldk, const void* v, int ldv, void* o, int ldo,
+                    void* lse, int B, int H, int Tq, int Tk, int dh, int causal, float scale, float drop_p,
+                    uint64_t drop_seed, capdec_stream_t stream);
+int capdec_attn_bwd(const void* q, int ldq, const void* k, int ldk, const void* v, int ldv, const void* o, int ldo,
+                    const void* dout, int lddo, const void* lse, void* delta, void* dq, int lddq, void* dk, int lddk,
+                    void* dv, int lddv, int B, int H, int Tq, int Tk, int dh, int causal, float scale, float drop_p,
+                    uint64_t drop_seed, capdec_stream_t stream);
+
+/* ---- label-smoothed softmax cross-entropy, forward + backward in one pass -------------------------
+ * Per row m of logits [M,V] (row stride ldl) with target y = targets[m] (int64):
+ *   loss_rows[m] = lse(z) - (1-eps)*z_y - (eps/V)*sum_v z_v
+ *   dlogits[m,v] = grad_scale * (softmax(z)_v - (1-eps)*[v==y] - eps/V)     (may alias logits; NULL = skip)
+ * Replaces ref train.py:41-50 (dense one-hot, log_softmax, product, mean over ALL B*T rows, PAD
+ * included) and its autograd backward; the mean is capdec_mean() over loss_rows.
+ */
+int capdec_softmax_ce(const void* logits, int ldl, const int64_t* targets, void* loss_rows, void* dlogits, int lddl,
+                      int M, int V, float eps, float grad_scale, capdec_stream_t stream);
+/* out[0] = scale * sum(x[0..n)) with a fixed (deterministic) reduction tree; workspace of
+ * capdec_reduce_workspace_bytes() bytes. */
+size_t capdec_reduce_workspace_bytes(void);
+int capdec_sum(const void* x, size_t n, float scale, void* out, void* workspace, size_t workspace_bytes,
+               capdec_stream_t stream);
+
+/* ---- gradient clipping + AdamW over a flat parameter block ---------------------------------------
+ * capdec_sumsq: out[0] = sum(g^2) (deterministic).  capdec_adamw: one fused pass
+ *   coef = min(1, max_norm / (sqrt(*gnorm_sq) + 1e-6))  (1 if gnorm_sq == NULL)   ref train.py:56
+ *   g = coef*g; p *= 1 - lr*wd; m = b1*m + (1-b1)*g; v = b2*v + (1-b2)*g*g;
+ *   p -= lr/(1-b1^step) * m / (sqrt(v)/sqrt(1-b2^step) + eps)                     ref main.py:95
+ * (torch.optim.AdamW single-tensor formula).  No host synchronisation: the norm stays on device.
+ */
+int capdec_sumsq(const void* g, size_t n, void* out, void* workspace, size_t workspace_bytes, capdec_stream_t stream);
+/* g *= min(1, max_norm/(sqrt(*gnorm_sq)+1e-6)) in place, for callers that keep torch.optim (ref train.py:56-59). */
+int capdec_clip_scale(void* g, size_t n, const void* gnorm_sq, float max_norm, capdec_stream_t stream);
+int capdec_adamw(void* p, const void* g, void* m, void* v, size_t n, float lr, float beta1, float beta2, float eps,
+                 float weight_decay, int step, const void* gnorm_sq, float max_norm, capdec_stream_t stream);
+
+/* ---- elementwise helpers for the sub-module-at-a-time call path ---------------------------------
+ * capdec_pe_add: out[r,:] = dropout(x[r,:] + pe[t0 + (r/div)%mod, :]) over x viewed as [R,d]
+ *   (seq-first [T,B,d]: div=B, mod=T -- PositionalEncoding.forward, ref models.py:17-19).
+ * capdec_act_dropout_bwd: out[i] = dy[i] * keep(i)/(1-p) * (pre ? gelu_erf'(pre[i]) : 1): the
+ *   gradient through Dropout(GELU(.)) of ref models.py:40-41, 70-71 when a Linear is called alone.
+ */
+int capdec_pe_add(const void* x, const void* pe, void* out, int R, int d, int div, int mod, int t0, float drop_p,
+                  uint64_t drop_seed, capdec_stream_t stream);
+int capdec_act_dropout_bwd(const void* dy, const void* pre, void* out, size_t n, float drop_p, uint64_t drop_seed,
+                           capdec_stream_t stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* CAPDEC_H_ */

@@ -1,0 +1,210 @@
+#!/usr/bin/env python3
+"""Headline benchmark: teacher-forced training throughput of the caption decoder (images/s).
+
+    python bench.py --gpus N --steps K --warmup W
+
+Workload at every N: BASELINE.json configs[1] ("C2") per GPU -- synthetic 7x7x2048 grid features
+(S = 49 memory positions), hidden 512, 8 heads, 6 layers, vocab 10k, max len 20, batch 256 per GPU,
+fp32, dropout 0.1 ACTIVE (the reference trains in model.train(), ref train.py:15), full step =
+forward + label-smoothed loss + backward + gradient all-reduce (N > 1) + global-norm clip + AdamW.
+Weak scaling: per-GPU batch is fixed; value = all ranks' images / max-over-ranks time.
+
+One JSON line on rank 0 (contract in the task statement), plus:
+  roofline     -- the dominant kernel (fp32 MFMA GEMM): algorithmic FLOPs of every GEMM launch of
+                  one step / their summed launch durations, measured live with HIP events on the
+                  launch stream in a separate instrumented step ("Measurement").
+  cpu_baseline -- the oracle (stock torch.nn on the host cores, the reference's own CPU path) on
+                  the same C2 step, bounded sample (N = 1, rank 0 only).
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import torch
+import torch.distributed as dist
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+CONFIGS = {
+    # name: (vocab, d_model, heads, layers, feature_dim, S, T, batch)
+    "c2": dict(vocab=10000, d=512, heads=8, layers=6, din=2048, S=49, T=20, batch=256),
+    "c1": dict(vocab=108, d=512, heads=8, layers=6, din=768, S=1, T=299, batch=32),
+    "c3": dict(vocab=30000, d=1024, heads=8, layers=6, din=512, S=196, T=20, batch=256),
+    "tiny": dict(vocab=50, d=64, heads=2, layers=2, din=24, S=5, T=12, batch=8),
+}
+PEAK_F32_MFMA_TFLOPS = 157.3  # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32, 64 FLOP/clk/SIMD
+PEAK_HBM_GBS = 8000.0
+
+
+def synth_batch(cfg, batch, device, rank):
+    g = torch.Generator().manual_seed(1234 + rank)
+    S, din, T, V = cfg["S"], cfg["din"], cfg["T"], cfg["vocab"]
+    feats = torch.randn((batch, din) if S == 1 else (batch, S, din), generator=g)
+    ids = torch.randint(5, V, (batch, T + 1), generator=g)
+    ids[:, 0] = 1
+    lens = torch.randint(min(8, T), T + 1, (batch,), generator=g)
+    pos = torch.arange(T + 1).unsqueeze(0)
+    ids = torch.where(pos == lens.unsqueeze(1), torch.full_like(ids, 2), ids)
+    ids = torch.where(pos > lens.unsqueeze(1), torch.zeros_like(ids), ids)
+    return feats.to(device), ids.to(device)
+
+
+def train_flops_per_image(cfg):
+    """forward FLOPs (2*MAC) per image; training = 3x."""
+    L, T, S, d, V, din = cfg["layers"], cfg["T"], cfg["S"], cfg["d"], cfg["vocab"], cfg["din"]
+    fwd = L * (28 * T * d * d + 4 * S * d * d + 2 * d * T * (T + 1) + 4 * T * S * d) + (4 * T * d * d + 4 * T * d * V) \
+        + S * (4 * din * d + 4 * d * d)
+    return 3.0 * fwd
+
+
+def cpu_baseline(cfg, steps=2):
+    """The reference's CPU path (stock torch.nn decoder, oracle/torch_oracle.py) on this box's host cores."""
+    from oracle.torch_oracle import OracleCaptionDecoder, train_step
+    threads = min(16, os.cpu_count() or 1)
+    torch.set_num_threads(threads)
+    torch.manual_seed(42)
+    model = OracleCaptionDecoder(cfg["vocab"], cfg["d"], cfg["heads"], cfg["layers"], cfg["din"]).train()
+    opt = torch.optim.AdamW(model.parameters(), lr=1e-3, weight_decay=0.01)
+    feats, ids = synth_batch(cfg, cfg["batch"], "cpu", 0)
+    train_step(model, opt, feats, ids)  # warm-up
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        train_step(model, opt, feats, ids)
+    dt = (time.perf_counter() - t0) / steps
+    return {"value": cfg["batch"] / dt, "unit": "images/s", "cores": threads, "kind": "port",
+            "sample": f"{steps} timed training steps (after 1 warm-up) of the same workload, batch {cfg['batch']}, "
+                      f"stock torch.nn fp32 on {threads} host threads, {dt:.2f} s/step"}
+
+
+def profile_step(trainer, feats, ids):
+    """One instrumented step: HIP-event duration of every GEMM / attention launch (on the launch stream)."""
+    from imagecaption_amd import ops
+    ops.PROFILE = []
+    trainer.step(feats, ids)
+    torch.cuda.synchronize()
+    rec, ops.PROFILE = ops.PROFILE, None
+    agg = {}
+    for kind, work, nbytes, e0, e1 in rec:
+        cls = kind.split("_")[0] + "_" + kind.split("_")[1]
+        a = agg.setdefault(cls, [0, 0.0, 0.0, 0.0])
+        a[0] += 1
+        a[1] += work
+        a[2] += nbytes
+        a[3] += e0.elapsed_time(e1) * 1e-3
+    detail = {}
+    for kind, work, nbytes, e0, e1 in rec:
+        d = detail.setdefault(kind, [0, 0.0, 0.0, 0.0])
+        d[0] += 1
+        d[1] += work
+        d[2] += nbytes
+        d[3] += e0.elapsed_time(e1) * 1e-3
+    return agg, detail
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--config", default="c2", choices=sorted(CONFIGS))
+    ap.add_argument("--batch", type=int, default=0, help="per-GPU batch (default: the config's)")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-dropout", action="store_true", help="eval-mode step (parity runs only; not the metric)")
+    ap.add_argument("--detail", action="store_true", help="print the per-shape kernel table to stderr")
+    args = ap.parse_args()
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs an MI355X: the capdec ops have no CPU fallback")
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+
+    from imagecaption_amd import ImageCaptioningModel
+    from imagecaption_amd.trainer import CaptionTrainer
+
+    cfg = dict(CONFIGS[args.config])
+    if args.batch:
+        cfg["batch"] = args.batch
+    torch.manual_seed(42)
+    model = ImageCaptioningModel(cfg["vocab"], cfg["d"], cfg["heads"], cfg["layers"], feature_dim=cfg["din"]).to(dev)
+    model.train()
+    trainer = CaptionTrainer(model, dropout=0.0 if args.no_dropout else 0.1, seed=42)
+    feats, ids = synth_batch(cfg, cfg["batch"], dev, rank)
+
+    for _ in range(args.warmup):
+        trainer.step(feats, ids)
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        loss = trainer.step(feats, ids)
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    if world > 1:
+        t = torch.tensor([dt], dtype=torch.float64, device=dev)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dt = float(t.item())
+    loss_val = float(loss.item())
+
+    out = None
+    if rank == 0:
+        ms = dt / args.steps * 1e3
+        value = cfg["batch"] * world * args.steps / dt
+        agg, detail = profile_step(trainer, feats, ids)
+        gemm_flops = sum(a[1] for k, a in agg.items() if k.startswith("gemm"))
+        gemm_time = sum(a[3] for k, a in agg.items() if k.startswith("gemm"))
+        gemm_n = sum(a[0] for k, a in agg.items() if k.startswith("gemm"))
+        ach = gemm_flops / gemm_time / 1e12 if gemm_time > 0 else 0.0
+        attn = {k: a for k, a in agg.items() if k.startswith("attn")}
+        attn_b = sum(a[2] for a in attn.values())
+        attn_t = sum(a[3] for a in attn.values())
+        vk = f"gemm_nt_{cfg['batch'] * cfg['T']}x{cfg['vocab']}x{2 * cfg['d']}"
+        vocab = detail.get(vk)
+        out = {
+            "metric": "train_images_per_sec", "value": value, "unit": "images/s", "n_gpus": world,
+            "steps": args.steps, "warmup": args.warmup, "ms_per_step": ms, "higher_is_better": True,
+            "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "config": {"workload": f"BASELINE.json configs[1] (C2): 7x7x2048 grid features, hidden {cfg['d']}, "
+                                   f"{cfg['layers']} layers, vocab {cfg['vocab']}, len {cfg['T']}, batch "
+                                   f"{cfg['batch']}/GPU, teacher-forced train step incl. dropout, clip, AdamW"
+                       if args.config == "c2" else args.config,
+                       "global_batch": cfg["batch"] * world, "seq_len": cfg["T"], "memory_len": cfg["S"],
+                       "parallelism": f"dp{world}", "params": trainer.n_params},
+            "loss": loss_val,
+            "step_tflops_algorithmic": train_flops_per_image(cfg) * value / 1e12,
+            "roofline": {"bound": "mfma", "achieved": ach, "peak": PEAK_F32_MFMA_TFLOPS, "unit": "TFLOP/s",
+                         "frac": ach / PEAK_F32_MFMA_TFLOPS, "traffic": None,
+                         "kernel": "gemm_f32_kernel (all launches of one step)", "launches_per_step": gemm_n,
+                         "gemm_ms_per_step": gemm_time * 1e3},
+            "vocab_gemm": ({"tflops": vocab[1] / vocab[3] / 1e12, "ms": vocab[3] * 1e3 / vocab[0],
+                            "frac_of_f32_mfma_peak": vocab[1] / vocab[3] / 1e12 / PEAK_F32_MFMA_TFLOPS}
+                           if vocab else None),
+            "attention": {"bound": "hbm", "achieved": attn_b / attn_t / 1e9 if attn_t else 0.0, "peak": PEAK_HBM_GBS,
+                          "unit": "GB/s", "frac": (attn_b / attn_t / 1e9 / PEAK_HBM_GBS) if attn_t else 0.0,
+                          "ms_per_step": attn_t * 1e3, "launches_per_step": sum(a[0] for a in attn.values())},
+        }
+        if args.detail:
+            for k, d in sorted(detail.items(), key=lambda kv: -kv[1][3]):
+                print(f"{k:42s} n={d[0]:3d} {d[3] * 1e3:8.3f} ms  {d[1] / d[3] / 1e12:7.2f} TF/s"
+                      + (f"  {d[2] / d[3] / 1e9:8.1f} GB/s" if d[2] else ""), file=sys.stderr)
+        if world == 1 and not args.no_cpu_baseline:
+            out["cpu_baseline"] = cpu_baseline(cfg)
+        print(json.dumps(out), flush=True)
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -24,7 +24,7 @@ class DecoderStackFn(torch.autograd.Function):
         nk = len(engine.LAYER_KEYS)
         layers = [dict(zip(engine.LAYER_KEYS, params[i * nk:(i + 1) * nk])) for i in range(nl)]
         norm_w, norm_b = params[nl * nk], params[nl * nk + 1]
-        need = torch.is_grad_enabled() and any(t.requires_grad for t in (tgt, memory) + tuple(params))
+        need = any(ctx.needs_input_grad)
         save = {} if need else None
         x, mem = _flat2(tgt), _flat2(memory)
         y = engine.stack_fwd(layers, norm_w, norm_b, x, mem, B, T, S, H, causal, dp, save)
@@ -51,7 +51,7 @@ class ProjectionFn(torch.autograd.Function):
     @staticmethod
     def forward(ctx, features, dp, *params):
         P = dict(zip(engine.PROJ_KEYS, params))
-        need = torch.is_grad_enabled() and any(t.requires_grad for t in (features,) + tuple(params))
+        need = any(ctx.needs_input_grad)
         save = {} if need else None
         out = engine.proj_fwd(P, _flat2(features), dp, save)
         if need:
@@ -73,7 +73,7 @@ class HeadFn(torch.autograd.Function):
     @staticmethod
     def forward(ctx, x, dp, *params):
         P = dict(zip(engine.HEAD_KEYS, params))
-        need = torch.is_grad_enabled() and any(t.requires_grad for t in (x,) + tuple(params))
+        need = any(ctx.needs_input_grad)
         save = {} if need else None
         logits = engine.head_fwd(P, _flat2(x), dp, save)
         if need:
@@ -126,7 +126,7 @@ class LinearFn(torch.autograd.Function):
     def forward(ctx, x, weight, bias, act, p, seed):
         x2 = _flat2(x)
         pre = None
-        need = torch.is_grad_enabled()
+        need = any(ctx.needs_input_grad)
         if act == ACT_GELU and need:
             pre = torch.empty((x2.shape[0], weight.shape[0]), dtype=torch.float32, device=x.device)
         y = ops.linear_fwd(x2, weight, bias, act=act, pre=pre, drop_p=p, seed=seed)

@@ -16,6 +16,27 @@ __all__ = ["gemm", "linear_fwd", "linear_dgrad", "linear_wgrad", "layernorm_fwd"
            "act_dropout_bwd"]
 
 
+# Optional per-launch timing (bench.py): when PROFILE is a list, GEMM / attention launches are
+# bracketed by events on torch's current stream -- the stream the kernels are launched on.
+PROFILE = None
+
+
+class _Timed:
+    def __init__(self, kind, work, nbytes=0):
+        self.rec = None
+        if PROFILE is not None:
+            self.rec = (kind, work, nbytes, torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True))
+
+    def __enter__(self):
+        if self.rec is not None:
+            self.rec[3].record()
+
+    def __exit__(self, *a):
+        if self.rec is not None:
+            self.rec[4].record()
+            PROFILE.append(self.rec)
+
+
 def _req(t, name, dtype=torch.float32):
     if not t.is_cuda:
         raise _capi.CapdecError(f"{name}: tensor is on {t.device}; the capdec ops run on the GPU only (no CPU fallback)")
@@ -60,9 +81,10 @@ def gemm(a, b, trans_a, trans_b, out=None, bias=None, addend=None, pre=None, aux
     l = lib()
     need = l.capdec_gemm_workspace_bytes(M, N, K)
     ws = _capi.workspace(need, a.device) if need else None
-    check(l.capdec_gemm(int(trans_a), int(trans_b), M, N, K, ptr(a), a.stride(0), ptr(b), b.stride(0), ptr(out),
-                        out.stride(0), C.byref(ep), F32, ptr(ws), ws.numel() if ws is not None else 0, stream()),
-          "capdec_gemm")
+    with _Timed(f"gemm_{'t' if trans_a else 'n'}{'t' if trans_b else 'n'}_{M}x{N}x{K}", 2.0 * M * N * K):
+        check(l.capdec_gemm(int(trans_a), int(trans_b), M, N, K, ptr(a), a.stride(0), ptr(b), b.stride(0), ptr(out),
+                            out.stride(0), C.byref(ep), F32, ptr(ws), ws.numel() if ws is not None else 0, stream()),
+              "capdec_gemm")
     return out
 
 
@@ -151,9 +173,12 @@ def attn_fwd(q, k, v, B, H, Tq, Tk, causal, drop_p=0.0, seed=0, out=None, save_l
     dh = D // H
     o = torch.empty((B * Tq, D), dtype=torch.float32, device=q.device) if out is None else out
     lse = torch.empty((B, H, Tq), dtype=torch.float32, device=q.device) if save_lse else None
-    check(lib().capdec_attn_fwd(ptr(q), q.stride(0), ptr(k), k.stride(0), ptr(v), v.stride(0), ptr(o), o.stride(0),
-                                ptr(lse), B, H, Tq, Tk, dh, int(causal), 1.0 / math.sqrt(dh), float(drop_p), int(seed),
-                                stream()), "capdec_attn_fwd")
+    # algorithmic bytes: read Q, K, V, write O
+    with _Timed(f"attn_fwd_{'causal' if causal else 'cross'}_{Tq}x{Tk}", 4.0 * B * H * Tq * Tk * dh,
+                4.0 * B * D * (2 * Tq + 2 * Tk)):
+        check(lib().capdec_attn_fwd(ptr(q), q.stride(0), ptr(k), k.stride(0), ptr(v), v.stride(0), ptr(o), o.stride(0),
+                                    ptr(lse), B, H, Tq, Tk, dh, int(causal), 1.0 / math.sqrt(dh), float(drop_p),
+                                    int(seed), stream()), "capdec_attn_fwd")
     return o, lse
 
 
@@ -165,10 +190,13 @@ def attn_bwd(q, k, v, o, do, lse, B, H, Tq, Tk, causal, drop_p=0.0, seed=0, dq=N
     dk = torch.empty((B * Tk, D), dtype=torch.float32, device=q.device) if dk is None else dk
     dv = torch.empty((B * Tk, D), dtype=torch.float32, device=q.device) if dv is None else dv
     delta = torch.empty((B, H, Tq), dtype=torch.float32, device=q.device)
-    check(lib().capdec_attn_bwd(ptr(q), q.stride(0), ptr(k), k.stride(0), ptr(v), v.stride(0), ptr(o), o.stride(0),
-                                ptr(do), do.stride(0), ptr(lse), ptr(delta), ptr(dq), dq.stride(0), ptr(dk),
-                                dk.stride(0), ptr(dv), dv.stride(0), B, H, Tq, Tk, dh, int(causal),
-                                1.0 / math.sqrt(dh), float(drop_p), int(seed), stream()), "capdec_attn_bwd")
+    # algorithmic bytes: read Q, K, V, O, dO; write dQ, dK, dV
+    with _Timed(f"attn_bwd_{'causal' if causal else 'cross'}_{Tq}x{Tk}", 10.0 * B * H * Tq * Tk * dh,
+                4.0 * B * D * (4 * Tq + 4 * Tk)):
+        check(lib().capdec_attn_bwd(ptr(q), q.stride(0), ptr(k), k.stride(0), ptr(v), v.stride(0), ptr(o), o.stride(0),
+                                    ptr(do), do.stride(0), ptr(lse), ptr(delta), ptr(dq), dq.stride(0), ptr(dk),
+                                    dk.stride(0), ptr(dv), dv.stride(0), B, H, Tq, Tk, dh, int(causal),
+                                    1.0 / math.sqrt(dh), float(drop_p), int(seed), stream()), "capdec_attn_bwd")
     return dq, dk, dv
 
 
@@ -186,13 +214,6 @@ def softmax_ce(logits, targets, eps=0.1, grad_scale=None, want_grad=True, in_pla
                                   dl.stride(0) if dl is not None else 0, M, V, float(eps), float(gs), stream()),
           "capdec_softmax_ce")
     return loss_rows, dl
-
-
-def _reduce(fn, x, *extra):
-    out = torch.empty(1, dtype=torch.float32, device=x.device)
-    l = lib()
-    ws = _capi.workspace(l.capdec_reduce_workspace_bytes(), x.device)
-    return out, ws
 
 
 def reduce_sum(x, scale=1.0):

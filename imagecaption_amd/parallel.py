@@ -1,0 +1,106 @@
+"""Data-parallel plumbing: flat parameter / gradient blocks, backward-ordered buckets, and the
+bucketed gradient all-reduce (RCCL over xGMI on the GPU box; gloo in the CPU tests).
+
+Device-agnostic on purpose: nothing here computes, it only lays tensors out and issues
+``torch.distributed`` collectives, so the N>1 logic is testable with world_size-2 gloo on CPU.
+
+The reference has no distributed code at all; the one exchange step of the
+path is the gradient all-reduce(sum), placed after backward and BEFORE the global-norm clip
+(ref train.py:56) so every rank clips by the same global norm.
+"""
+import torch
+import torch.distributed as dist
+
+ALIGN = 64  # elements (256 B): every parameter view stays 16-byte aligned for the float4 kernels
+
+
+class FlatParams:
+    """Lay the parameters of ``groups`` = [(bucket_name, [params...]), ...] out in one contiguous block.
+
+    After construction every ``p.data`` is a view into ``flat_p`` and every ``p.grad`` a view into
+    ``flat_g`` (padding between tensors stays zero forever), so ``state_dict()``, checkpoints and
+    stock optimizers keep working on the same storage.  ``bucket_ranges[i] = (name, start, end)``.
+    """
+
+    def __init__(self, groups, device=None):
+        total, self.bucket_ranges, self.placed = 0, [], []
+        for name, plist in groups:
+            start = total
+            for p in plist:
+                self.placed.append((p, total))
+                total += (p.numel() + ALIGN - 1) // ALIGN * ALIGN
+            self.bucket_ranges.append((name, start, total))
+        dev = device if device is not None else self.placed[0][0].device
+        self.flat_p = torch.zeros(total, dtype=torch.float32, device=dev)
+        self.flat_g = torch.zeros(total, dtype=torch.float32, device=dev)
+        for p, off in self.placed:
+            view = self.flat_p[off:off + p.numel()].view_as(p)
+            view.copy_(p.data)
+            p.data = view
+            p.grad = self.flat_g[off:off + p.numel()].view_as(p)
+        self.n_params = sum(p.numel() for p, _ in self.placed)
+        self.total = total
+
+
+class BucketReducer:
+    """all-reduce(sum) of gradient buckets, each issued as soon as the caller says it is complete.
+
+    On CUDA/HIP tensors the collective runs on a side stream ordered after the work enqueued so far
+    on the current stream, so it overlaps the rest of backward; ``finish()`` joins it back.
+    """
+
+    def __init__(self, flat_g, bucket_ranges, process_group=None, overlap=True):
+        self.flat_g, self.ranges, self.pg = flat_g, bucket_ranges, process_group
+        self.world = dist.get_world_size(process_group) if (dist.is_available() and dist.is_initialized()) else 1
+        self.side = torch.cuda.Stream(device=flat_g.device) if (overlap and self.world > 1 and flat_g.is_cuda) else None
+        self.works = []
+
+    def reduce(self, idx):
+        if self.world == 1:
+            return
+        _, a, b = self.ranges[idx]
+        buf = self.flat_g[a:b]
+        if self.side is not None:
+            ev = torch.cuda.Event()
+            ev.record()
+            self.side.wait_event(ev)
+            with torch.cuda.stream(self.side):
+                self.works.append(dist.all_reduce(buf, op=dist.ReduceOp.SUM, group=self.pg, async_op=True))
+        else:
+            self.works.append(dist.all_reduce(buf, op=dist.ReduceOp.SUM, group=self.pg, async_op=True))
+
+    def finish(self):
+        for w in self.works:
+            w.wait()
+        self.works = []
+        if self.side is not None:
+            torch.cuda.current_stream().wait_stream(self.side)
+
+
+def shard_indices(n, rank, world, epoch=0, seed=42, shuffle=True):
+    """Seeded per-rank partition of range(n) replacing DataLoader(shuffle=True) (ref main.py:63-70).
+
+    Every rank draws the same permutation and takes a strided slice; the tail is dropped so all
+    ranks run the same number of equal-sized batches (mean-of-means stays exact).
+    """
+    g = torch.Generator().manual_seed(seed + epoch)
+    perm = torch.randperm(n, generator=g) if shuffle else torch.arange(n)
+    per = n // world
+    return perm[: per * world].view(per, world)[:, rank].contiguous()
+
+
+def shard_range(n, rank, world):
+    """Contiguous image shard for inference (no collective): [start, end) of rank."""
+    base, rem = divmod(n, world)
+    start = rank * base + min(rank, rem)
+    return start, start + base + (1 if rank < rem else 0)
+
+
+def decoder_param_groups(model):
+    """Buckets in the order backward completes them last-to-first: embed+proj | layer0..L-1 | norm+head."""
+    dec = model.transformer_decoder
+    groups = [("embed+proj", [model.embedding.weight] + list(model.feature_projection.parameters()))]
+    for i, layer in enumerate(dec.layers):
+        groups.append((f"layer{i}", list(layer.parameters())))
+    groups.append(("norm+head", list(dec.norm.parameters()) + list(model.output_layer.parameters())))
+    return groups

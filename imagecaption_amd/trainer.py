@@ -1,0 +1,116 @@
+"""Teacher-forced training step of the caption decoder, MI355X-first.
+
+One ``CaptionTrainer.step`` is the body of the reference's loop (ref train.py:24-61): shift,
+forward, label-smoothed loss over ALL B*T positions, backward, global-norm clip at 1.0, AdamW --
+but as a fixed launch plan over flat HBM-resident blocks instead of autograd over module tensors:
+
+* parameters, gradients and both Adam moments each live in ONE contiguous fp32 block (288 GB of
+  HBM makes fragmentation pointless); the module's ``nn.Parameter``s are views into it, so
+  ``state_dict()`` / checkpoints / the reference's own optimizer objects keep working;
+* weight-gradient GEMMs write straight into the flat gradient block (no ``.grad`` accumulation
+  pass, no ``zero_grad``); clip + AdamW is one streaming kernel reading the norm from device memory
+  (the reference's ``loss.item()`` / clip host syncs are gone: nothing here synchronises);
+* data parallel: the block is cut into buckets in backward order (head, layer L-1 .. 0,
+  projection + embedding); each bucket's RCCL all-reduce(sum) is issued on a side stream as soon as
+  its last gradient kernel is enqueued, overlapping the rest of backward.  The loss gradient is
+  pre-scaled by 1/(rows * world) so the summed gradient IS the global-batch mean gradient and every
+  rank clips by the same global norm (placement: before ref train.py:56).
+"""
+import torch
+import torch.distributed as dist
+
+from . import engine, ops
+from .engine import DropoutPlan
+from .parallel import BucketReducer, FlatParams, decoder_param_groups
+
+
+class CaptionTrainer:
+    def __init__(self, model, lr=1e-3, betas=(0.9, 0.999), eps=1e-8, weight_decay=0.01, max_norm=1.0,
+                 smooth_factor=0.1, dropout=0.1, seed=0, process_group=None, overlap=True):
+        self.model = model
+        self.lr, self.betas, self.eps, self.wd = lr, betas, eps, weight_decay
+        self.max_norm, self.smooth, self.p, self.seed = max_norm, smooth_factor, dropout, seed
+        self.pg = process_group
+        self.world = dist.get_world_size(process_group) if (dist.is_available() and dist.is_initialized()) else 1
+        self.step_count = 0
+        dec = model.transformer_decoder
+        self.nhead, self.nl = dec.nhead, len(dec.layers)
+        # ---- flat blocks, ordered so that backward finishes buckets back to front -----------------
+        groups = decoder_param_groups(model)
+        seen = {id(p) for _, plist in groups for p in plist}
+        extra = [n for n, p in model.named_parameters() if id(p) not in seen]
+        if extra:
+            raise RuntimeError(f"CaptionTrainer: parameters outside the decoder path: {extra}")
+        self.flat = FlatParams(groups)
+        self.flat_p, self.flat_g = self.flat.flat_p, self.flat.flat_g
+        self.bucket_ranges, self.n_params = self.flat.bucket_ranges, self.flat.n_params
+        self.flat_m = torch.zeros_like(self.flat_p)
+        self.flat_v = torch.zeros_like(self.flat_p)
+        dev = self.flat_p.device
+        self.gnorm_sq = torch.zeros(1, dtype=torch.float32, device=dev)
+        self.reducer = BucketReducer(self.flat_g, self.bucket_ranges, process_group, overlap)
+        self._refresh_views()
+
+    def _refresh_views(self):
+        m = self.model
+        self.P_layers = [layer.param_dict() for layer in m.transformer_decoder.layers]
+        self.G_layers = [{k: v.grad for k, v in P.items()} for P in self.P_layers]
+        fp = m.feature_projection
+        self.P_proj = dict(zip(engine.PROJ_KEYS, [fp[0].weight, fp[0].bias, fp[1].weight, fp[1].bias, fp[4].weight,
+                                                  fp[4].bias, fp[5].weight, fp[5].bias]))
+        self.G_proj = {k: v.grad for k, v in self.P_proj.items()}
+        ol = m.output_layer
+        self.P_head = dict(zip(engine.HEAD_KEYS, [ol[0].weight, ol[0].bias, ol[3].weight, ol[3].bias]))
+        self.G_head = {k: v.grad for k, v in self.P_head.items()}
+
+    # ---- one iteration of ref train.py:24-61 ---------------------------------------------------------
+    def forward_backward(self, features, captions, train=True, keep_logits=False):
+        m = self.model
+        tgt_in = captions[:, :-1].contiguous()   # ref train.py:29
+        tgt_out = captions[:, 1:].contiguous()   # ref train.py:30
+        B, T = tgt_in.shape
+        dp = DropoutPlan(self.p if train else 0.0, self.seed, self.step_count)
+        f2 = features.reshape(-1, features.shape[-1])
+        S = 1 if features.dim() == 2 else features.shape[1]
+        sv_proj, sv_stack, sv_head = {}, {}, {}
+        mem = engine.proj_fwd(self.P_proj, f2, dp, sv_proj)
+        x = ops.embed_fwd(tgt_in, m.embedding.weight, m.pos_encoder.table(), 0, dp.p, dp.seed(engine.S_EMBED))
+        dec = m.transformer_decoder
+        y = engine.stack_fwd(self.P_layers, dec.norm.weight, dec.norm.bias, x.view(B * T, -1), mem, B, T, S, self.nhead,
+                             True, dp, sv_stack)
+        logits = engine.head_fwd(self.P_head, y, dp, sv_head)
+        keep = logits.clone() if keep_logits else None
+        rows, dlogits = ops.softmax_ce(logits, tgt_out.view(-1), self.smooth, grad_scale=1.0 / (B * T * self.world),
+                                       in_place=True)
+        loss = ops.reduce_sum(rows, 1.0 / (B * T))
+        nb = len(self.bucket_ranges)
+        dy = engine.head_bwd(self.P_head, self.G_head, sv_head, dlogits, dp)
+
+        def after_layer(l):
+            if l == self.nl - 1:
+                self.reducer.reduce(nb - 1)  # head + final norm are complete once layer L-1 started
+            self.reducer.reduce(1 + l)
+
+        dx, dmem = engine.stack_bwd(self.P_layers, self.G_layers, dec.norm.weight, dec.norm.bias, dec.norm.weight.grad,
+                                    dec.norm.bias.grad, sv_stack, dy, mem, B, T, S, self.nhead, True, dp, after_layer)
+        engine.proj_bwd(self.P_proj, self.G_proj, sv_proj, dmem, dp)
+        ops.embed_bwd(tgt_in, dx.view(B, T, -1), m.embedding.weight.shape[0], dp.p, dp.seed(engine.S_EMBED),
+                      dE=m.embedding.weight.grad)
+        self.reducer.reduce(0)
+        self.reducer.finish()
+        return loss, keep
+
+    def optimizer_step(self):
+        self.step_count += 1
+        ops.sumsq(self.flat_g, out=self.gnorm_sq)
+        ops.adamw(self.flat_p, self.flat_g, self.flat_m, self.flat_v, self.step_count, self.lr, self.betas, self.eps,
+                  self.wd, gnorm_sq=self.gnorm_sq, max_norm=self.max_norm)
+
+    def step(self, features, captions, train=True):
+        """Returns the (device-resident, un-synchronised) mean loss of this rank's batch."""
+        loss, _ = self.forward_backward(features, captions, train=train)
+        self.optimizer_step()
+        return loss
+
+    def grad_norm(self):
+        return self.gnorm_sq.sqrt()

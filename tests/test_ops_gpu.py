@@ -221,9 +221,10 @@ def test_attention_fwd_bwd(B, H, Tq, Tk, dh, causal):
     assert relerr(o, o_ref.reshape(-1, D)) < 1e-5
     assert relerr(lse, lse_ref) < 1e-5
     dq, dk, dv = ops.attn_bwd(qd, kd, vd, o, dod, lse, B, H, Tq, Tk, causal)
-    assert relerr(dq, gq.reshape(-1, D)) < 2e-5
-    assert relerr(dk, gk.reshape(-1, D)) < 2e-5
-    assert relerr(dv, gv.reshape(-1, D)) < 2e-5
+    # Tk == 1 makes dq and dk exactly 0 in exact arithmetic: measure against max(|ref|, 1)
+    for got, ref in ((dq, gq), (dk, gk), (dv, gv)):
+        ref = ref.reshape(-1, D)
+        assert float((got.double().cpu() - ref).abs().max()) < 2e-5 * max(float(ref.abs().max()), 1.0)
 
 
 def test_attention_packed_qkv_slices():

@@ -28,71 +28,156 @@ __global__ __launch_bounds__(256) void embed_fwd_kernel(const int64_t* __restric
     }
 }
 
-// One block per vocabulary row v: scan all ids in index order, add matching rows.  The scan
-// order is fixed, so the sum is bitwise reproducible; rows of absent tokens are written as zeros
-// (no memset needed).  A presence bitmap built by the first kernel lets absent rows skip the scan.
-__global__ __launch_bounds__(256) void embed_present_kernel(const int64_t* __restrict__ ids, int* __restrict__ present,
-                                                             int BT, int V) {
-    const int i = blockIdx.x * 256 + threadIdx.x;
-    if (i < BT) {
-        int64_t id = ids[i];
-        id = id < 0 ? 0 : (id >= V ? V - 1 : id);
-        present[id] = 1;
+// ---- backward: deterministic scatter-add ------------------------------------------------------
+// Rows are grouped by token with a stable counting sort (rank = number of earlier rows with the
+// same id), so dE[v] is the sum of its rows in row order whatever the launch geometry.  Work is
+// spread over fixed 32-row chunks of the SORTED list (heavy tokens such as <PAD>, 80 % of the
+// reference's positions, would otherwise serialise one workgroup): each wave reduces one chunk
+// into per-(token, chunk) partial rows, then one workgroup per token adds that token's partials
+// in chunk order.  No float atomics: the result is bitwise reproducible.
+__device__ __forceinline__ int clamp_id(int64_t id, int V) { return (int)(id < 0 ? 0 : (id >= V ? V - 1 : id)); }
+
+__global__ __launch_bounds__(256) void embed_rank_kernel(const int64_t* __restrict__ ids, int* __restrict__ count,
+                                                          int* __restrict__ rank, int BT, int V) {
+    __shared__ int tile[256];
+    const int m = blockIdx.x * 256 + threadIdx.x;
+    const int my = m < BT ? clamp_id(ids[m], V) : -1;
+    int r = 0;
+    for (int t = 0; t <= (int)blockIdx.x; ++t) {
+        const int j = t * 256 + threadIdx.x;
+        __syncthreads();
+        tile[threadIdx.x] = j < BT ? clamp_id(ids[j], V) : -2;
+        __syncthreads();
+        const int lim = t < (int)blockIdx.x ? 256 : (int)threadIdx.x;  // only rows before m
+#pragma unroll 8
+        for (int k = 0; k < 256; ++k) r += (k < lim && tile[k] == my) ? 1 : 0;
+    }
+    if (m < BT) {
+        rank[m] = r;
+        atomicAdd(&count[my], 1);  // integer atomics: order-independent result
     }
 }
 
-__global__ __launch_bounds__(256) void embed_bwd_kernel(const int64_t* __restrict__ ids, const float* __restrict__ dout,
-                                                         float* __restrict__ dE, const int* __restrict__ present, int BT,
-                                                         int d, int V, Dropout drop) {
-    const int v = blockIdx.x;
-    float* dst = dE + (size_t)v * d;
-    if (!present[v]) {
-        for (int c = threadIdx.x; c < d; c += 256) dst[c] = 0.f;
-        return;
-    }
-    // columns handled by this thread: c = threadIdx.x + 256*i, i < 8  (d <= 2048)
-    float acc[8];
-#pragma unroll
-    for (int i = 0; i < 8; ++i) acc[i] = 0.f;
-    for (int base = 0; base < BT; base += 256) {
-        const int i = base + threadIdx.x;
-        int64_t id = -1;
-        if (i < BT) {
-            id = ids[i];
-            id = id < 0 ? 0 : (id >= V ? V - 1 : id);
-        }
-        // every wave needs the matches of all 4 waves of this chunk, in index order
-        __shared__ unsigned long long masks[4];
-        const unsigned long long m = __ballot(id == v);
-        if ((threadIdx.x & 63) == 0) masks[threadIdx.x >> 6] = m;
+__global__ __launch_bounds__(1024) void embed_scan_kernel(const int* __restrict__ count, int* __restrict__ offset, int V) {
+    __shared__ int sums[1024];
+    const int per = (V + 1023) / 1024;
+    const int lo = threadIdx.x * per, hi = min(V, lo + per);
+    int s = 0;
+    for (int i = lo; i < hi; ++i) s += count[i];
+    sums[threadIdx.x] = s;
+    __syncthreads();
+    for (int o = 1; o < 1024; o <<= 1) {
+        const int v = threadIdx.x >= o ? sums[threadIdx.x - o] : 0;
         __syncthreads();
+        sums[threadIdx.x] += v;
+        __syncthreads();
+    }
+    int run = sums[threadIdx.x] - s;
+    for (int i = lo; i < hi; ++i) {
+        offset[i] = run;
+        run += count[i];
+    }
+    if (threadIdx.x == 1023) offset[V] = sums[1023];
+}
+
+__global__ __launch_bounds__(256) void embed_order_kernel(const int64_t* __restrict__ ids, const int* __restrict__ offset,
+                                                           const int* __restrict__ rank, int* __restrict__ order, int BT,
+                                                           int V) {
+    const int m = blockIdx.x * 256 + threadIdx.x;
+    if (m < BT) order[offset[clamp_id(ids[m], V)] + rank[m]] = m;
+}
+
+// one wave per 32-position chunk of the sorted list; part[j] (row j of [BT,d]) receives the sum of
+// the run of equal tokens that STARTS (within this chunk) at sorted position j.
+__global__ __launch_bounds__(256) void embed_partial_kernel(const int64_t* __restrict__ ids, const int* __restrict__ order,
+                                                             const float* __restrict__ dout, float* __restrict__ part,
+                                                             int BT, int d, int V, Dropout drop) {
+    const int lane = threadIdx.x & 63;
+    const int chunk = blockIdx.x * 4 + (threadIdx.x >> 6);
+    const int j0 = chunk * 32;
+    if (j0 >= BT) return;
+    const int n = min(32, BT - j0);
+    int my_row = 0, my_id = -1;
+    if (lane < n) {
+        my_row = order[j0 + lane];
+        my_id = clamp_id(ids[my_row], V);
+    }
+    const int nq = d >> 2;
+    for (int q0 = 0; q0 < nq; q0 += 64) {  // 256 columns per pass
+        const int q = q0 + lane;
+        const bool act = q < nq;
+        float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+        int head = 0;
+        for (int g = 0; g < n; g += 4) {
+            float4 v[4];
+            int rows[4], vid[4];
 #pragma unroll
-        for (int w = 0; w < 4; ++w) {
-            unsigned long long mm = masks[w];
-            while (mm) {
-                const int b = __ffsll((long long)mm) - 1;
-                mm &= mm - 1;
-                const int row = base + w * 64 + b;
-                const float* src = dout + (size_t)row * d;
+            for (int u = 0; u < 4; ++u) {
+                rows[u] = __shfl(my_row, min(g + u, n - 1), 64);
+                vid[u] = __shfl(my_id, min(g + u, n - 1), 64);
+                v[u] = (act && g + u < n) ? reinterpret_cast<const float4*>(dout + (size_t)rows[u] * d)[q]
+                                          : make_float4(0.f, 0.f, 0.f, 0.f);
+            }
 #pragma unroll
-                for (int k = 0; k < 8; ++k) {
-                    const int c = threadIdx.x + 256 * k;
-                    if (c < d) {
-                        float g = src[c];
-                        if (drop.on()) g = drop.apply(g, (uint32_t)row * (uint32_t)d + (uint32_t)c);
-                        acc[k] += g;
+            for (int u = 0; u < 4; ++u) {
+                const int j = g + u;
+                if (j < n) {
+                    float a[4] = {v[u].x, v[u].y, v[u].z, v[u].w};
+                    if (drop.on()) {
+#pragma unroll
+                        for (int c = 0; c < 4; ++c)
+                            a[c] = drop.apply(a[c], (uint32_t)rows[u] * (uint32_t)d + (uint32_t)(q * 4 + c));
+                    }
+                    acc.x += a[0]; acc.y += a[1]; acc.z += a[2]; acc.w += a[3];
+                    const int nxt = __shfl(my_id, min(j + 1, n - 1), 64);
+                    if (j == n - 1 || nxt != vid[u]) {  // wave-uniform: end of a run
+                        if (act) reinterpret_cast<float4*>(part + (size_t)(j0 + head) * d)[q] = acc;
+                        acc = make_float4(0.f, 0.f, 0.f, 0.f);
+                        head = j + 1;
                     }
                 }
             }
         }
-        __syncthreads();
-    }
-#pragma unroll
-    for (int k = 0; k < 8; ++k) {
-        const int c = threadIdx.x + 256 * k;
-        if (c < d) dst[c] = acc[k];
     }
 }
+
+// one workgroup per token: dE[v] = part[a] + part[next multiple of 32 after a] + ... (< b), in order;
+// the list is cut into 4 contiguous shares (one per wave), combined in wave order.
+__global__ __launch_bounds__(256) void embed_combine_kernel(const int* __restrict__ offset, const float* __restrict__ part,
+                                                             float* __restrict__ dE, int d) {
+    __shared__ __attribute__((aligned(16))) float sh[4][2048];
+    const int v = blockIdx.x;
+    const int a = offset[v], b = offset[v + 1];
+    float* dst = dE + (size_t)v * d;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int nq = d >> 2;
+    if (a == b) {
+        for (int q = threadIdx.x; q < nq; q += 256) reinterpret_cast<float4*>(dst)[q] = make_float4(0.f, 0.f, 0.f, 0.f);
+        return;
+    }
+    const int first_b = (a / 32 + 1) * 32;                       // first chunk boundary after a
+    const int nh = 1 + (first_b < b ? (b - 1 - first_b) / 32 + 1 : 0);  // heads: a, first_b, first_b+32, ...
+    const int share = (nh + 3) / 4;
+    const int h0 = wave * share, h1 = min(nh, h0 + share);
+    for (int q = lane; q < nq; q += 64) {
+        float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+        for (int h = h0; h < h1; ++h) {
+            const int pos = h == 0 ? a : first_b + (h - 1) * 32;
+            const float4 t = reinterpret_cast<const float4*>(part + (size_t)pos * d)[q];
+            acc.x += t.x; acc.y += t.y; acc.z += t.z; acc.w += t.w;
+        }
+        reinterpret_cast<float4*>(&sh[wave][0])[q] = acc;
+    }
+    __syncthreads();
+    for (int q = threadIdx.x; q < nq; q += 256) {
+        const float4 p0 = reinterpret_cast<const float4*>(&sh[0][0])[q], p1 = reinterpret_cast<const float4*>(&sh[1][0])[q];
+        const float4 p2 = reinterpret_cast<const float4*>(&sh[2][0])[q], p3 = reinterpret_cast<const float4*>(&sh[3][0])[q];
+        reinterpret_cast<float4*>(dst)[q] = make_float4(((p0.x + p1.x) + p2.x) + p3.x, ((p0.y + p1.y) + p2.y) + p3.y,
+                                                        ((p0.z + p1.z) + p2.z) + p3.z, ((p0.w + p1.w) + p2.w) + p3.w);
+    }
+}
+
+static size_t embed_ws_ints(int BT, int V) { return ((size_t)2 * V + 1 + 2 * (size_t)BT + 3) / 4 * 4; }
 
 }  // namespace capdec
 
@@ -110,25 +195,39 @@ extern "C" int capdec_embed_fwd(const int64_t* ids, const void* E, const void* p
     return check_launch("capdec_embed_fwd");
 }
 
-extern "C" size_t capdec_embed_bwd_workspace_bytes(int V) { return V > 0 ? (size_t)V * sizeof(int) : 0; }
+extern "C" size_t capdec_embed_bwd_workspace_bytes(int B, int T, int d, int V) {
+    if (B <= 0 || T <= 0 || d <= 0 || V <= 0) return 0;
+    return (embed_ws_ints(B * T, V) + (size_t)B * T * d) * sizeof(float);
+}
 
 extern "C" int capdec_embed_bwd(const int64_t* ids, const void* dout, void* dE, int B, int T, int d, int V, float drop_p,
                                 uint64_t drop_seed, void* workspace, size_t workspace_bytes, capdec_stream_t stream) {
     CAPDEC_REQUIRE(ids && dout && dE, "capdec_embed_bwd: null pointer");
-    CAPDEC_REQUIRE(B > 0 && T > 0 && V > 0 && d > 0 && d <= 2048, "capdec_embed_bwd: bad shape");
+    CAPDEC_REQUIRE(B > 0 && T > 0 && V > 0 && d > 0 && d % 4 == 0 && d <= 2048, "capdec_embed_bwd: bad shape");
+    CAPDEC_REQUIRE(aligned16(dout) && aligned16(dE) && aligned16(workspace), "capdec_embed_bwd: unaligned");
     CAPDEC_REQUIRE((uint64_t)B * T * d < (1ull << 32), "capdec_embed_bwd: B*T*d exceeds 2^32");
-    if (!workspace || workspace_bytes < (size_t)V * sizeof(int)) {
-        set_error("capdec_embed_bwd: needs %zu workspace bytes, got %zu", (size_t)V * sizeof(int), workspace_bytes);
+    const int BT = B * T;
+    const size_t need = capdec_embed_bwd_workspace_bytes(B, T, d, V);
+    if (!workspace || workspace_bytes < need) {
+        set_error("capdec_embed_bwd: needs %zu workspace bytes, got %zu", need, workspace_bytes);
         return CAPDEC_ERR_WORKSPACE;
     }
+    int* count = (int*)workspace;
+    int* offset = count + V;
+    int* rank = offset + V + 1;
+    int* order = rank + BT;
+    float* part = (float*)workspace + embed_ws_ints(BT, V);
     hipStream_t st = (hipStream_t)stream;
-    const int BT = B * T;
-    if (hipMemsetAsync(workspace, 0, (size_t)V * sizeof(int), st) != hipSuccess) {
+    if (hipMemsetAsync(count, 0, (size_t)V * sizeof(int), st) != hipSuccess) {
         set_error("capdec_embed_bwd: memset failed");
         return CAPDEC_ERR_LAUNCH;
     }
-    hipLaunchKernelGGL(embed_present_kernel, dim3((BT + 255) / 256), dim3(256), 0, st, ids, (int*)workspace, BT, V);
-    hipLaunchKernelGGL(embed_bwd_kernel, dim3(V), dim3(256), 0, st, ids, (const float*)dout, (float*)dE,
-                       (const int*)workspace, BT, d, V, make_dropout(drop_p, drop_seed));
+    const int nb = (BT + 255) / 256;
+    hipLaunchKernelGGL(embed_rank_kernel, dim3(nb), dim3(256), 0, st, ids, count, rank, BT, V);
+    hipLaunchKernelGGL(embed_scan_kernel, dim3(1), dim3(1024), 0, st, (const int*)count, offset, V);
+    hipLaunchKernelGGL(embed_order_kernel, dim3(nb), dim3(256), 0, st, ids, (const int*)offset, (const int*)rank, order, BT, V);
+    hipLaunchKernelGGL(embed_partial_kernel, dim3((BT + 127) / 128), dim3(256), 0, st, ids, (const int*)order,
+                       (const float*)dout, part, BT, d, V, make_dropout(drop_p, drop_seed));
+    hipLaunchKernelGGL(embed_combine_kernel, dim3(V), dim3(256), 0, st, (const int*)offset, (const float*)part, (float*)dE, d);
     return check_launch("capdec_embed_bwd");
 }

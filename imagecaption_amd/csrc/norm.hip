@@ -7,7 +7,7 @@
 
 namespace capdec {
 
-constexpr int LN_MAX_BLOCKS = 512;
+constexpr int LN_MAX_BLOCKS = 256;
 
 template <int NV>
 __global__ __launch_bounds__(256) void ln_fwd_kernel(const float* __restrict__ x, const float* __restrict__ gamma,
@@ -151,17 +151,27 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(const float* __restrict__ d
     }
 }
 
+// 64 columns per block, 4 row groups: each thread sums a strided quarter of the partial rows,
+// then the four are combined in a fixed order (deterministic).
 __global__ __launch_bounds__(256) void ln_bwd_finalize_kernel(const float* __restrict__ part, float* __restrict__ dgamma,
                                                                float* __restrict__ dbeta, int nblk, int d) {
-    const int c = blockIdx.x * 256 + threadIdx.x;
-    if (c >= d) return;
+    __shared__ float sh[2][4][64];
+    const int cl = threadIdx.x & 63, rg = threadIdx.x >> 6;
+    const int c = blockIdx.x * 64 + cl;
     float a = 0.f, b = 0.f;
-    for (int k = 0; k < nblk; ++k) {
-        a += part[((size_t)k * 2 + 0) * d + c];
-        b += part[((size_t)k * 2 + 1) * d + c];
+    if (c < d) {
+        for (int k = rg; k < nblk; k += 4) {
+            a += part[((size_t)k * 2 + 0) * d + c];
+            b += part[((size_t)k * 2 + 1) * d + c];
+        }
     }
-    dgamma[c] = a;
-    dbeta[c] = b;
+    sh[0][rg][cl] = a;
+    sh[1][rg][cl] = b;
+    __syncthreads();
+    if (rg == 0 && c < d) {
+        dgamma[c] = (sh[0][0][cl] + sh[0][1][cl]) + (sh[0][2][cl] + sh[0][3][cl]);
+        dbeta[c] = (sh[1][0][cl] + sh[1][1][cl]) + (sh[1][2][cl] + sh[1][3][cl]);
+    }
 }
 
 static int ln_blocks(int M) {
@@ -229,7 +239,7 @@ extern "C" int capdec_layernorm_bwd(const void* dy, const void* x, const void* g
 #undef CALL
     int rc = check_launch("capdec_layernorm_bwd");
     if (rc) return rc;
-    hipLaunchKernelGGL(ln_bwd_finalize_kernel, dim3((d + 255) / 256), dim3(256), 0, st, (const float*)workspace,
+    hipLaunchKernelGGL(ln_bwd_finalize_kernel, dim3((d + 63) / 64), dim3(256), 0, st, (const float*)workspace,
                        (float*)dgamma, (float*)dbeta, nblk, d);
     return check_launch("capdec_layernorm_bwd(finalize)");
 }

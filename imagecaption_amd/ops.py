@@ -160,7 +160,7 @@ def embed_bwd(ids, dout, V, drop_p=0.0, seed=0, dE=None):
     if dE is None:
         dE = torch.empty((V, d), dtype=torch.float32, device=dout.device)
     l = lib()
-    ws = _capi.workspace(l.capdec_embed_bwd_workspace_bytes(V), dout.device)
+    ws = _capi.workspace(l.capdec_embed_bwd_workspace_bytes(B, T, d, V), dout.device)
     check(l.capdec_embed_bwd(ptr(ids), ptr(_req(dout, "embed_bwd.dout")), ptr(dE), B, T, d, V, float(drop_p), int(seed),
                              ptr(ws), ws.numel(), stream()), "capdec_embed_bwd")
     return dE

@@ -90,7 +90,7 @@ int capdec_layernorm_bwd(const void* dy, const void* x, const void* gamma, const
  */
 int capdec_embed_fwd(const int64_t* ids, const void* E, const void* pe, void* out, int B, int T, int d, int V,
                      int t0, float drop_p, uint64_t drop_seed, capdec_stream_t stream);
-size_t capdec_embed_bwd_workspace_bytes(int V);
+size_t capdec_embed_bwd_workspace_bytes(int B, int T, int d, int V);
 int capdec_embed_bwd(const int64_t* ids, const void* dout, void* dE, int B, int T, int d, int V, float drop_p,
                      uint64_t drop_seed, void* workspace, size_t workspace_bytes, capdec_stream_t stream);
 

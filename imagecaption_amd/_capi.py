@@ -27,6 +27,7 @@ SIGNATURES = {
     "capdec_abi_version": (_i, []),
     "capdec_last_error": (C.c_char_p, []),
     "capdec_gemm_workspace_bytes": (_sz, [_i, _i, _i]),
+    "capdec_gemm_tune": (_i, [_i, _i, _i, _i]),
     "capdec_gemm": (_i, [_i, _i, _i, _i, _i, _vp, _i, _vp, _i, _vp, _i, C.POINTER(Epilogue), _i, _vp, _sz, _vp]),
     "capdec_layernorm_bwd_workspace_bytes": (_sz, [_i, _i]),
     "capdec_layernorm_fwd": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _f, _i, _f, _u64, _vp]),

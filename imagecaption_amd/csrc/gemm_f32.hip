@@ -33,7 +33,6 @@ struct GemmParams {
     int tiles_n;
 };
 
-constexpr int GBK = 16;
 
 __device__ __forceinline__ float epilogue_apply(const GemmParams& p, float v, int m, int n) {
     if (p.bias) v += p.bias[n];
@@ -59,7 +58,7 @@ __device__ __forceinline__ float4 load4(const float* ptr, bool ok, int rem) {
 }
 
 // AK / BKM: operand is k-contiguous in memory (A stored [M,K]; B stored [N,K]).
-template <int BM, int BN, bool AK, bool BKM, bool VEC>
+template <int BM, int BN, int GBK, bool AK, bool BKM, bool VEC>
 __global__ __launch_bounds__(256) void gemm_f32_kernel(GemmParams p) {
     constexpr int NT = 256;
     constexpr int TM = BM / 64, TN = BN / 64;  // 32x32 accumulators per wave in each direction
@@ -85,7 +84,19 @@ __global__ __launch_bounds__(256) void gemm_f32_kernel(GemmParams p) {
         const int q = nwg >> 3, r = nwg & 7, xcd = wg & 7;
         wg = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (wg >> 3);
     }
-    const int m0 = (wg / p.tiles_n) * BM, n0 = (wg % p.tiles_n) * BN;
+    // grouped order inside an XCD's run: 8 row panels x all column panels, row panel fastest, so
+    // the ~160 workgroups resident on an XCD share few A and B panels in its 4 MiB L2
+    int tile_m, tile_n;
+    {
+        const int tiles_m = nwg / p.tiles_n;
+        const int per_group = 8 * p.tiles_n;
+        const int gid = wg / per_group, first_m = gid * 8;
+        const int gsz = min(tiles_m - first_m, 8);
+        const int in_g = wg - gid * per_group;
+        tile_m = first_m + in_g % gsz;
+        tile_n = in_g / gsz;
+    }
+    const int m0 = tile_m * BM, n0 = tile_n * BN;
     const int kbeg = blockIdx.z * p.ksplit;
     const int kend = min(p.K, kbeg + p.ksplit);
     const int nk = (kend - kbeg + GBK - 1) / GBK;
@@ -154,7 +165,7 @@ __global__ __launch_bounds__(256) void gemm_f32_kernel(GemmParams p) {
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
 
-    const bool do_colsum = (!AK) && p.colsum != nullptr && (wg % p.tiles_n) == 0;
+    const bool do_colsum = (!AK) && p.colsum != nullptr && tile_n == 0;
     float csum = 0.f;
 
     if (nk > 0) {
@@ -190,15 +201,17 @@ __global__ __launch_bounds__(256) void gemm_f32_kernel(GemmParams p) {
                     bf[j] = make_float4(s[0], s[B_LD], s[2 * B_LD], s[3 * B_LD]);
                 }
             }
+            // k-step outermost: consecutive MFMAs hit different accumulators (no back-to-back dependency)
 #pragma unroll
-            for (int i = 0; i < TM; ++i)
+            for (int c = 0; c < 4; ++c)
 #pragma unroll
-                for (int j = 0; j < TN; ++j) {
-                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[i].x, bf[j].x, acc[i][j], 0, 0, 0);
-                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[i].y, bf[j].y, acc[i][j], 0, 0, 0);
-                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[i].z, bf[j].z, acc[i][j], 0, 0, 0);
-                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[i].w, bf[j].w, acc[i][j], 0, 0, 0);
-                }
+                for (int i = 0; i < TM; ++i)
+#pragma unroll
+                    for (int j = 0; j < TN; ++j) {
+                        const float av = c == 0 ? af[i].x : c == 1 ? af[i].y : c == 2 ? af[i].z : af[i].w;
+                        const float bv = c == 0 ? bf[j].x : c == 1 ? bf[j].y : c == 2 ? bf[j].z : bf[j].w;
+                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(av, bv, acc[i][j], 0, 0, 0);
+                    }
         }
         if (do_colsum && tid < BM) {
 #pragma unroll
@@ -250,44 +263,55 @@ __global__ __launch_bounds__(256) void gemm_splitk_reduce_kernel(GemmParams p, i
 
 // ---- host side: tile / split-K choice ---------------------------------------------------------
 struct GemmPlan {
-    int bm, bn, split, ksplit;
+    int bm, bn, bk, split, ksplit;
 };
 
 static inline int cdiv(int a, int b) { return (a + b - 1) / b; }
 
-// MFMA-bound cost model: every SIMD of the 256 CUs runs one wave per resident block; a wave owns
-// (bm/64)*(bn/64) accumulators for K/split reduction steps.  Cost = max work on any SIMD.
+static int g_force_bm = 0, g_force_bn = 0, g_force_split = 0, g_force_bk = 0;  // tuning hook (capdec_gemm_tune)
+
+// MFMA-bound cost model, calibrated on tools/gemm_sweep.py (profiles/r01_gemm_sweep.txt).  A CU
+// with r co-resident workgroups runs r waves per SIMD; one wave per SIMD cannot cover its own
+// barrier / load stalls, so the matrix pipe's utilisation u(r) rises with r.  Cost = rounds of
+// workgroups per CU x work per workgroup / u, plus the split-K partial round trip.
 static GemmPlan plan_gemm(int M, int N, int K) {
     static const int cand[4][2] = {{128, 128}, {128, 64}, {64, 128}, {64, 64}};
-    GemmPlan best{128, 128, 1, K};
+    static const double util[5] = {0.0, 0.55, 0.80, 0.97, 1.0};
+    const int bk = g_force_bk ? g_force_bk : 16;
+    if (g_force_bm) {
+        int split = g_force_split > 0 ? g_force_split : 1;
+        int ks = cdiv(cdiv(K, split), bk) * bk;
+        return GemmPlan{g_force_bm, g_force_bn, bk, cdiv(K, ks), ks};
+    }
+    GemmPlan best{128, 128, bk, 1, K};
     double best_cost = 1e300;
     for (int c = 0; c < 4; ++c) {
         const int bm = cand[c][0], bn = cand[c][1];
         const int tiles = cdiv(M, bm) * cdiv(N, bn);
         const double units = (bm / 64) * (bn / 64);
+        const int rmax = c == 0 ? 3 : 4;
         for (int split = 1; split <= 32; split *= 2) {
-            int ks = cdiv(cdiv(K, split), GBK) * GBK;
+            int ks = cdiv(cdiv(K, split), bk) * bk;
             if (split > 1 && ks < 128) break;
             const int s_eff = cdiv(K, ks);
             const long blocks = (long)tiles * s_eff;
-            const double per_cu = (double)cdiv((int)blocks, 256);
-            // k-loop work + fixed prologue/epilogue per block (in units of one 32x32x16 k-tile)
-            double cost = per_cu * units * (cdiv(ks, GBK) + 6.0);
-            if (s_eff > 1) cost += 0.02 * (double)M * N * s_eff / 65536.0 + 4.0;  // partial write + reduce pass
-            // mild preference for larger tiles (less L2 traffic) on ties
-            cost *= 1.0 + 0.02 * (c);
+            const int per_cu = cdiv((int)(blocks > 2000000 ? 2000000 : blocks), 256);
+            const int r = per_cu < rmax ? per_cu : rmax;
+            double cost = per_cu * units * (cdiv(ks, 16) + 4.0) / util[r];
+            if (s_eff > 1) cost += 1.3e-6 * (double)M * N * s_eff + 8.0;  // partial write + reduce pass
+            cost *= 1.0 + 0.01 * c;  // ties -> larger tiles (less L2 traffic)
             if (cost < best_cost) {
                 best_cost = cost;
-                best = GemmPlan{bm, bn, s_eff, ks};
+                best = GemmPlan{bm, bn, bk, s_eff, ks};
             }
         }
     }
     return best;
 }
 
-template <int BM, int BN>
+template <int BM, int BN, int BK>
 static void launch_cfg(const GemmParams& p, bool AK, bool BKM, bool vec, dim3 grid, hipStream_t st) {
-#define CAPDEC_LAUNCH(ak, bk, v) hipLaunchKernelGGL((gemm_f32_kernel<BM, BN, ak, bk, v>), grid, dim3(256), 0, st, p)
+#define CAPDEC_LAUNCH(ak, bk, v) hipLaunchKernelGGL((gemm_f32_kernel<BM, BN, BK, ak, bk, v>), grid, dim3(256), 0, st, p)
     if (vec) {
         if (AK && BKM) CAPDEC_LAUNCH(true, true, true);
         else if (AK && !BKM) CAPDEC_LAUNCH(true, false, true);
@@ -305,6 +329,14 @@ static void launch_cfg(const GemmParams& p, bool AK, bool BKM, bool vec, dim3 gr
 }  // namespace capdec
 
 using namespace capdec;
+
+extern "C" int capdec_gemm_tune(int bm, int bn, int split, int bk) {
+    const bool ok = ((bm == 0) || ((bm == 64 || bm == 128) && (bn == 64 || bn == 128) && split >= 1 && split <= 64)) &&
+                    (bk == 0 || bk == 16 || bk == 32);
+    CAPDEC_REQUIRE(ok, "capdec_gemm_tune: unsupported tile %dx%d split %d bk %d", bm, bn, split, bk);
+    g_force_bm = bm; g_force_bn = bn; g_force_split = split; g_force_bk = bk;
+    return CAPDEC_OK;
+}
 
 extern "C" size_t capdec_gemm_workspace_bytes(int M, int N, int K) {
     if (M <= 0 || N <= 0 || K <= 0) return 0;
@@ -359,10 +391,17 @@ extern "C" int capdec_gemm(int transA, int transB, int M, int N, int K, const vo
     const bool AK = !transA, BKM = transB != 0;
     dim3 grid(cdiv(M, pl.bm) * p.tiles_n, 1, pl.split);
     hipStream_t st = (hipStream_t)stream;
-    if (pl.bm == 128 && pl.bn == 128) launch_cfg<128, 128>(p, AK, BKM, vec, grid, st);
-    else if (pl.bm == 128 && pl.bn == 64) launch_cfg<128, 64>(p, AK, BKM, vec, grid, st);
-    else if (pl.bm == 64 && pl.bn == 128) launch_cfg<64, 128>(p, AK, BKM, vec, grid, st);
-    else launch_cfg<64, 64>(p, AK, BKM, vec, grid, st);
+    if (pl.bk == 32) {
+        if (pl.bm == 128 && pl.bn == 128) launch_cfg<128, 128, 32>(p, AK, BKM, vec, grid, st);
+        else if (pl.bm == 128 && pl.bn == 64) launch_cfg<128, 64, 32>(p, AK, BKM, vec, grid, st);
+        else if (pl.bm == 64 && pl.bn == 128) launch_cfg<64, 128, 32>(p, AK, BKM, vec, grid, st);
+        else launch_cfg<64, 64, 32>(p, AK, BKM, vec, grid, st);
+    } else {
+        if (pl.bm == 128 && pl.bn == 128) launch_cfg<128, 128, 16>(p, AK, BKM, vec, grid, st);
+        else if (pl.bm == 128 && pl.bn == 64) launch_cfg<128, 64, 16>(p, AK, BKM, vec, grid, st);
+        else if (pl.bm == 64 && pl.bn == 128) launch_cfg<64, 128, 16>(p, AK, BKM, vec, grid, st);
+        else launch_cfg<64, 64, 16>(p, AK, BKM, vec, grid, st);
+    }
     int rc = check_launch("capdec_gemm");
     if (rc) return rc;
     if (pl.split > 1) {

@@ -62,6 +62,10 @@ typedef struct capdec_epilogue {
 } capdec_epilogue;
 
 size_t capdec_gemm_workspace_bytes(int M, int N, int K);
+/* Tuning hook (process-global, not thread-safe): force block tile bm x bn in {64,128}^2 and a split-K
+ * factor (and k-tile bk in {0 = default, 16, 32}) for every following capdec_gemm call; bm = 0
+ * restores the built-in cost model. */
+int capdec_gemm_tune(int bm, int bn, int split, int bk);
 int capdec_gemm(int transA, int transB, int M, int N, int K, const void* A, int lda, const void* B, int ldb,
                 void* C, int ldc, const capdec_epilogue* ep, int dtype, void* workspace, size_t workspace_bytes,
                 capdec_stream_t stream);

@@ -1,0 +1,46 @@
+"""Tile / split-K sweep of capdec_gemm over the shapes of the C2 training step (tuning aid, GPU only)."""
+import sys, os, itertools
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import torch
+from imagecaption_amd import ops, _capi
+
+SHAPES = [  # (ta, tb, M, N, K)
+    (0, 1, 5120, 10000, 1024), (0, 0, 5120, 1024, 10000), (1, 0, 10000, 1024, 5120),
+    (0, 1, 5120, 512, 512), (0, 0, 5120, 512, 512), (1, 0, 512, 512, 5120),
+    (0, 1, 5120, 2048, 512), (0, 1, 5120, 512, 2048), (1, 0, 2048, 512, 5120), (1, 0, 512, 2048, 5120),
+    (0, 1, 5120, 1536, 512), (1, 0, 1536, 512, 5120), (0, 1, 12544, 1024, 512), (1, 0, 1024, 512, 12544),
+    (0, 0, 12544, 512, 1024),
+]
+
+def timeit(fn, n=10):
+    fn(); torch.cuda.synchronize()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(n): fn()
+    e1.record(); torch.cuda.synchronize()
+    return e0.elapsed_time(e1) / n * 1e-3
+
+l = _capi.lib()
+for ta, tb, M, N, K in SHAPES:
+    a = torch.randn((K, M) if ta else (M, K), device="cuda")
+    b = torch.randn((N, K) if tb else (K, N), device="cuda")
+    out = torch.empty(M, N, device="cuda")
+    res = []
+    l.capdec_gemm_tune(0, 0, 0, 0)
+    t = timeit(lambda: ops.gemm(a, b, ta, tb, out=out))
+    res.append(("auto", t))
+    for (bm, bn), sp, bk in itertools.product([(128, 128), (128, 64), (64, 128), (64, 64)], [1, 2, 4, 8, 16], [16, 32]):
+        if sp > 1 and K // sp < 128: continue
+        if sp > 1 and M * N * sp * 4 > (1 << 30): continue
+        l.capdec_gemm_tune(bm, bn, sp, bk)
+        try:
+            t = timeit(lambda: ops.gemm(a, b, ta, tb, out=out))
+        except Exception as e:
+            continue
+        res.append((f"{bm}x{bn}x{bk}/s{sp}", t))
+    l.capdec_gemm_tune(0, 0, 0, 0)
+    fl = 2.0 * M * N * K
+    res.sort(key=lambda r: r[1])
+    auto = [r for r in res if r[0] == "auto"][0]
+    print(f"{'nt'[ta]}{'nt'[tb]} {M}x{N}x{K}: auto {auto[1]*1e6:7.1f}us {fl/auto[1]/1e12:6.1f}TF | best " +
+          "  ".join(f"{n} {t*1e6:.1f}us {fl/t/1e12:.1f}TF" for n, t in res[:4]), flush=True)

@@ -1,0 +1,108 @@
+"""N > 1 plumbing on CPU: flat blocks, bucketed all-reduce over gloo (world_size 2), sharding, seeds."""
+import os
+import socket
+
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+from imagecaption_amd.engine import DropoutPlan
+from imagecaption_amd.parallel import BucketReducer, FlatParams, shard_indices, shard_range
+from oracle.torch_oracle import OracleCaptionDecoder, label_smoothed_loss, synthetic_captions
+
+TINY = dict(vocab_size=50, d_model=64, nhead=2, num_decoder_layers=2, feature_dim=24)
+
+
+def _groups(model):
+    dec = model.transformer_decoder
+    groups = [("embed+proj", [model.embedding.weight] + list(model.feature_projection.parameters()))]
+    for i, layer in enumerate(dec.layers):
+        groups.append((f"layer{i}", list(layer.parameters())))
+    groups.append(("norm+head", list(dec.norm.parameters()) + list(model.output_layer.parameters())))
+    return groups
+
+
+def test_flat_params_views_and_alignment():
+    torch.manual_seed(0)
+    model = OracleCaptionDecoder(**TINY)
+    before = {n: p.detach().clone() for n, p in model.named_parameters()}
+    flat = FlatParams(_groups(model))
+    assert flat.n_params == sum(p.numel() for p in model.parameters())
+    assert [b[0] for b in flat.bucket_ranges] == ["embed+proj", "layer0", "layer1", "norm+head"]
+    for (n, p) in model.named_parameters():
+        assert torch.equal(p, before[n])
+        assert p.data_ptr() % 16 == 0 and p.grad.data_ptr() % 16 == 0
+        assert p.untyped_storage().data_ptr() == flat.flat_p.untyped_storage().data_ptr()
+    model.embedding.weight.data.add_(1.0)  # writes through to the flat block
+    assert flat.flat_p[: model.embedding.weight.numel()].view_as(model.embedding.weight)[0, 0] == before["embedding.weight"][0, 0] + 1
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def _dp_worker(rank, world, port, out):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    torch.set_num_threads(1)
+    torch.manual_seed(0)
+    model = OracleCaptionDecoder(**TINY).eval()
+    gen = torch.Generator().manual_seed(5)
+    B, T = 8, 12
+    feats = torch.randn(B, 5, 24, generator=gen)
+    caps = synthetic_captions(B, T, 50, gen, min_len=4)
+    # single-process reference: global batch, mean over all rows (ref train.py:50)
+    loss = label_smoothed_loss(model(feats, caps[:, :-1]), caps[:, 1:])
+    ref = torch.autograd.grad(loss, list(model.parameters()))
+    # data parallel: equal shards, local loss gradient pre-scaled by 1/(rows*world), summed over ranks
+    flat = FlatParams(_groups(model))
+    idx = shard_indices(B, rank, world, shuffle=False)
+    lf, lc = feats[idx], caps[idx]
+    logits = model(lf, lc[:, :-1])
+    local = label_smoothed_loss(logits, lc[:, 1:]) / world
+    local.backward()  # accumulates into the zero-initialised flat_g views
+    red = BucketReducer(flat.flat_g, flat.bucket_ranges)
+    assert red.world == world
+    for i in reversed(range(len(flat.bucket_ranges))):
+        red.reduce(i)
+    red.finish()
+    err = max(float((p.grad - r).abs().max() / (r.abs().max() + 1e-12)) for p, r in zip(model.parameters(), ref))
+    norm = flat.flat_g.norm()
+    norms = [torch.zeros(()) for _ in range(world)]
+    dist.all_gather(norms, norm)
+    out[rank] = (err, [float(n) for n in norms])
+    dist.destroy_process_group()
+
+
+def test_bucketed_allreduce_equals_global_batch_gradient_gloo_world2():
+    world, port = 2, _free_port()
+    with mp.Manager() as mgr:
+        out = mgr.dict()
+        mp.spawn(_dp_worker, args=(world, port, out), nprocs=world, join=True)
+        for rank in range(world):
+            err, norms = out[rank]
+            assert err < 1e-5, err
+            assert norms[0] == norms[1]  # every rank clips by the same global norm
+
+
+def test_sharding_helpers():
+    a, b = shard_indices(101, 0, 2, epoch=3), shard_indices(101, 1, 2, epoch=3)
+    assert len(a) == len(b) == 50 and not set(a.tolist()) & set(b.tolist())
+    assert not torch.equal(a, shard_indices(101, 0, 2, epoch=4))
+    spans = [shard_range(100000, r, 8) for r in range(8)]
+    assert spans[0][0] == 0 and spans[-1][1] == 100000
+    assert all(spans[i][1] == spans[i + 1][0] for i in range(7))
+    assert sum(e - s for s, e in [shard_range(10, r, 4) for r in range(4)]) == 10
+
+
+def test_dropout_plan_seeds():
+    a, b = DropoutPlan(0.1, 42, 7), DropoutPlan(0.1, 42, 7)
+    assert a.seed(3) == b.seed(3) and a.seed(3) != a.seed(4)
+    assert DropoutPlan(0.1, 42, 8).seed(3) != a.seed(3)
+    assert DropoutPlan(0.0).p == 0.0
+    assert 0 <= a.seed(1000) < 2 ** 64

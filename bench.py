@@ -79,6 +79,35 @@ def cpu_baseline(cfg, steps=2):
                       f"stock torch.nn fp32 on {threads} host threads, {dt:.2f} s/step"}
 
 
+def decode_bench(model, cfg, dev, rank, world, images=1024, max_len=20):
+    """Beam-3 / beam-5 / greedy captions/s, KV-cached engine, images sharded per rank, no collective."""
+    from imagecaption_amd.decode import CaptionDecoder
+    dec = CaptionDecoder(model)
+    feats, _ = synth_batch(cfg, images, dev, 100 + rank)
+    res = {}
+    for name, fn in (("beam3", lambda: dec.beam(feats, beam=3, max_len=max_len)),
+                     ("beam5", lambda: dec.beam(feats, beam=5, max_len=max_len)),
+                     ("greedy", lambda: dec.greedy(feats, max_len=max_len))):
+        fn()
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        fn()
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+        dt = time.perf_counter() - t0
+        if world > 1:
+            t = torch.tensor([dt], dtype=torch.float64, device=dev)
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+            dt = float(t.item())
+        res[f"{name}_captions_per_sec"] = images * world / dt
+    res["images_per_gpu"], res["max_len"] = images, max_len
+    model.train()
+    return res
+
+
 def profile_step(trainer, feats, ids):
     """One instrumented step: HIP-event duration of every GEMM / attention launch (on the launch stream)."""
     from imagecaption_amd import ops
@@ -113,6 +142,8 @@ def main():
     ap.add_argument("--batch", type=int, default=0, help="per-GPU batch (default: the config's)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-dropout", action="store_true", help="eval-mode step (parity runs only; not the metric)")
+    ap.add_argument("--no-decode", action="store_true")
+    ap.add_argument("--decode-images", type=int, default=1024, help="images per GPU for the decode leg")
     ap.add_argument("--detail", action="store_true", help="print the per-shape kernel table to stderr")
     args = ap.parse_args()
 
@@ -156,6 +187,8 @@ def main():
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t.item())
     loss_val = float(loss.item())
+    decode = None if args.no_decode else decode_bench(model, cfg, dev, rank, world, images=args.decode_images,
+                                                      max_len=min(cfg["T"], 20))
 
     out = None
     if rank == 0:
@@ -182,6 +215,7 @@ def main():
                        "global_batch": cfg["batch"] * world, "seq_len": cfg["T"], "memory_len": cfg["S"],
                        "parallelism": f"dp{world}", "params": trainer.n_params},
             "loss": loss_val,
+            "decode": decode,
             "step_tflops_algorithmic": train_flops_per_image(cfg) * value / 1e12,
             "roofline": {"bound": "mfma", "achieved": ach, "peak": PEAK_F32_MFMA_TFLOPS, "unit": "TFLOP/s",
                          "frac": ach / PEAK_F32_MFMA_TFLOPS, "traffic": None,

@@ -1,0 +1,282 @@
+// KV-cached decode step kernels: single-query attention over the cache (self, through a beam
+// ancestry table; cross, over the per-image memory K/V shared by all beams), greedy argmax and the
+// beam-search top-k / reorder kernel.  See include/capdec.h (capdec_decode_attn, capdec_greedy_select,
+// capdec_beam_select).
+//
+// Beam reorder without moving the cache: K/V of position j always stay in the cache slot of the beam
+// row that computed them; anc[r][j] names that slot for the hypothesis now living in row r.  The
+// top-k kernel rewrites only the small int tables (ancestry, token history), never the
+// [rows, Tmax, 2d] cache -- the reorder costs O(W*T) ints per image instead of O(L*W*T*d) floats.
+#include "common.h"
+
+namespace capdec {
+
+struct DecodeAttnParams {
+    const float* q; int ldq;      // [R, >= H*dh]
+    const float* k; const float* v; int ldkv;  // key row stride (elements)
+    float* out; int ldo;
+    const int* anc;               // [R, Tmax] or nullptr (cross attention)
+    int R, H, Tmax, t, W, S;
+    float scale;
+};
+
+// one wave per (row, head); LPK = DH/4 lanes share one key (float4 each), 64/LPK keys per pass.
+template <int DH>
+__global__ __launch_bounds__(256) void decode_attn_kernel(DecodeAttnParams p) {
+    constexpr int LPK = DH / 4, KPI = 64 / LPK;
+    const int lane = threadIdx.x & 63;
+    const int item = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (item >= p.R * p.H) return;
+    const int r = item / p.H, h = item % p.H;
+    const int g = lane / LPK, e4 = lane % LPK;
+    const int nkeys = p.anc ? p.t + 1 : p.S;
+    float4 q4 = *reinterpret_cast<const float4*>(p.q + (size_t)r * p.ldq + h * DH + e4 * 4);
+    q4.x *= p.scale; q4.y *= p.scale; q4.z *= p.scale; q4.w *= p.scale;
+    float m = -INFINITY, l = 0.f;
+    float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+    for (int j0 = 0; j0 < nkeys; j0 += KPI) {
+        const int j = j0 + g;
+        const bool valid = j < nkeys;
+        size_t row = 0;
+        if (valid) {
+            if (p.anc) {
+                const int slot = j == p.t ? r : p.anc[(size_t)r * p.Tmax + j];
+                row = (size_t)slot * p.Tmax + j;
+            } else {
+                row = (size_t)(r / p.W) * p.S + j;
+            }
+        }
+        float4 k4 = make_float4(0.f, 0.f, 0.f, 0.f), v4 = k4;
+        if (valid) {
+            k4 = *reinterpret_cast<const float4*>(p.k + row * p.ldkv + h * DH + e4 * 4);
+            v4 = *reinterpret_cast<const float4*>(p.v + row * p.ldkv + h * DH + e4 * 4);
+        }
+        float s = (q4.x * k4.x + q4.y * k4.y) + (q4.z * k4.z + q4.w * k4.w);
+#pragma unroll
+        for (int o = 1; o < LPK; o <<= 1) s += __shfl_xor(s, o, 64);
+        s = valid ? s : -INFINITY;
+        float mi = s;
+#pragma unroll
+        for (int o = LPK; o < 64; o <<= 1) mi = fmaxf(mi, __shfl_xor(mi, o, 64));
+        const float mn = fmaxf(m, mi);  // finite: key 0 is always valid in the first pass
+        const float alpha = __expf(m - mn);
+        const float pj = valid ? __expf(s - mn) : 0.f;
+        float ps = pj;
+#pragma unroll
+        for (int o = LPK; o < 64; o <<= 1) ps += __shfl_xor(ps, o, 64);
+        l = l * alpha + ps;
+        acc.x = acc.x * alpha + pj * v4.x; acc.y = acc.y * alpha + pj * v4.y;
+        acc.z = acc.z * alpha + pj * v4.z; acc.w = acc.w * alpha + pj * v4.w;
+        m = mn;
+    }
+#pragma unroll
+    for (int o = LPK; o < 64; o <<= 1) {
+        acc.x += __shfl_xor(acc.x, o, 64); acc.y += __shfl_xor(acc.y, o, 64);
+        acc.z += __shfl_xor(acc.z, o, 64); acc.w += __shfl_xor(acc.w, o, 64);
+    }
+    if (g == 0) {
+        const float inv = 1.f / l;
+        *reinterpret_cast<float4*>(p.out + (size_t)r * p.ldo + h * DH + e4 * 4) =
+            make_float4(acc.x * inv, acc.y * inv, acc.z * inv, acc.w * inv);
+    }
+}
+
+// ---- block-wide "best candidate" reduction: higher score wins, ties -> lower index -------------
+struct Cand {
+    float s;
+    int i;
+};
+__device__ __forceinline__ bool better(const Cand& a, const Cand& b) { return a.s > b.s || (a.s == b.s && a.i < b.i); }
+__device__ __forceinline__ Cand wave_best(Cand c) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) {
+        Cand d;
+        d.s = __shfl_xor(c.s, o, 64);
+        d.i = __shfl_xor(c.i, o, 64);
+        if (better(d, c)) c = d;
+    }
+    return c;
+}
+__device__ __forceinline__ Cand block_best(Cand c, Cand* sh) {  // 256 threads
+    c = wave_best(c);
+    __syncthreads();
+    if ((threadIdx.x & 63) == 0) sh[threadIdx.x >> 6] = c;
+    __syncthreads();
+    Cand b = sh[0];
+#pragma unroll
+    for (int w = 1; w < 4; ++w)
+        if (better(sh[w], b)) b = sh[w];
+    return b;
+}
+
+constexpr int TOK_PAD = 0, TOK_END = 2;  // ref dataset.py:112-116
+
+// one block per row: token = argmax(logits) (ties -> lowest id); a finished row emits PAD.
+__global__ __launch_bounds__(256) void greedy_select_kernel(const float* __restrict__ logits, int ldl, int* __restrict__ done,
+                                                             int* __restrict__ seq, int64_t* __restrict__ next_tok,
+                                                             float* __restrict__ gap, int V, int Tmax, int t) {
+    __shared__ Cand sh[4];
+    const int r = blockIdx.x;
+    const float* z = logits + (size_t)r * ldl;
+    Cand c{-INFINITY, 0x7fffffff};
+    for (int v = threadIdx.x; v < V; v += 256) {
+        Cand d{z[v], v};
+        if (better(d, c)) c = d;
+    }
+    const Cand b = block_best(c, sh);
+    // runner-up (for the recorded top-1/top-2 margin)
+    Cand c2{-INFINITY, 0x7fffffff};
+    for (int v = threadIdx.x; v < V; v += 256) {
+        Cand d{z[v], v};
+        if (v != b.i && better(d, c2)) c2 = d;
+    }
+    const Cand b2 = block_best(c2, sh);
+    if (threadIdx.x == 0) {
+        const int was_done = done[r];
+        const int tok = was_done ? TOK_PAD : b.i;
+        seq[(size_t)r * Tmax + t] = tok;
+        next_tok[r] = tok;
+        done[r] = was_done | (tok == TOK_END);
+        if (gap && !was_done) gap[r] = fminf(gap[r], b.s - b2.s);
+    }
+}
+
+// one block per image: top-W of {score[w] + log_softmax(logits[w])[v]} over W*V candidates.
+constexpr int MAXW = 8;
+__global__ __launch_bounds__(256) void beam_select_kernel(const float* __restrict__ logits, int ldl,
+                                                           const float* __restrict__ score_in, float* __restrict__ score_out,
+                                                           const int* __restrict__ fin_in, int* __restrict__ fin_out,
+                                                           const int* __restrict__ anc_in, int* __restrict__ anc_out,
+                                                           const int* __restrict__ seq_in, int* __restrict__ seq_out,
+                                                           int64_t* __restrict__ next_tok, float* __restrict__ gap, int W,
+                                                           int V, int Tmax, int t) {
+    __shared__ Cand sh[4];
+    __shared__ float red[4];
+    __shared__ float row_max[MAXW], row_logsum[MAXW], row_score[MAXW];
+    __shared__ int row_fin[MAXW];
+    __shared__ Cand picked[MAXW + 1];
+    const int n = blockIdx.x, tid = threadIdx.x;
+    const float NEG = -1.0e30f;
+    // 1. per-beam log-sum-exp (torch's log_softmax order: max, sum exp(z - max), log)
+    for (int w = 0; w < W; ++w) {
+        const float* z = logits + (size_t)(n * W + w) * ldl;
+        float mx = -INFINITY;
+        for (int v = tid; v < V; v += 256) mx = fmaxf(mx, z[v]);
+        mx = wave_max(mx);
+        __syncthreads();
+        if ((tid & 63) == 0) red[tid >> 6] = mx;
+        __syncthreads();
+        mx = fmaxf(fmaxf(red[0], red[1]), fmaxf(red[2], red[3]));
+        float se = 0.f;
+        for (int v = tid; v < V; v += 256) se += __expf(z[v] - mx);
+        se = wave_sum(se);
+        __syncthreads();
+        if ((tid & 63) == 0) red[tid >> 6] = se;
+        __syncthreads();
+        if (tid == 0) {
+            row_max[w] = mx;
+            row_logsum[w] = __logf((red[0] + red[1]) + (red[2] + red[3]));
+            row_score[w] = score_in[n * W + w];
+            row_fin[w] = fin_in[n * W + w];
+        }
+    }
+    __syncthreads();
+    // 2. per-thread top-(MAXW+1) over its strided share of the W*V candidates (flat index ascending);
+    //    the list length is a compile-time constant so it stays in registers
+    Cand loc[MAXW + 1];
+#pragma unroll
+    for (int k = 0; k <= MAXW; ++k) loc[k] = Cand{-INFINITY, 0x7fffffff};
+    const int total = W * V;
+    for (int f = tid; f < total; f += 256) {
+        const int w = f / V, v = f - w * V;
+        float s;
+        if (row_fin[w]) s = row_score[w] + (v == TOK_PAD ? 0.f : NEG);
+        else s = row_score[w] + ((logits[(size_t)(n * W + w) * ldl + v] - row_max[w]) - row_logsum[w]);
+        const Cand c{s, f};
+        if (better(c, loc[MAXW])) {
+            loc[MAXW] = c;
+#pragma unroll
+            for (int k = MAXW; k > 0; --k)
+                if (better(loc[k], loc[k - 1])) {
+                    const Cand tmp = loc[k]; loc[k] = loc[k - 1]; loc[k - 1] = tmp;
+                }
+        }
+    }
+    // 3. W+1 rounds of block-wide best: winner pops the head of its local list
+    for (int k = 0; k <= W; ++k) {
+        const Cand b = block_best(loc[0], sh);
+        if (loc[0].i == b.i && loc[0].s == b.s) {
+#pragma unroll
+            for (int q = 0; q < MAXW; ++q) loc[q] = loc[q + 1];
+            loc[MAXW] = Cand{-INFINITY, 0x7fffffff};
+        }
+        if (tid == 0) picked[k] = b;
+        __syncthreads();
+    }
+    // 4. write the new beam state; reorder = rewrite the int tables only
+    for (int k = 0; k < W; ++k) {
+        const Cand b = picked[k];
+        const int pw = b.i / V, tok = b.i - pw * V;
+        const int prow = n * W + pw, row = n * W + k;
+        for (int j = tid; j < t; j += 256) {
+            seq_out[(size_t)row * Tmax + j] = seq_in[(size_t)prow * Tmax + j];
+            anc_out[(size_t)row * Tmax + j] = anc_in[(size_t)prow * Tmax + j];
+        }
+        if (tid == 0) {
+            seq_out[(size_t)row * Tmax + t] = tok;
+            anc_out[(size_t)row * Tmax + t] = prow;
+            score_out[row] = b.s;
+            fin_out[row] = row_fin[pw] | (tok == TOK_END);
+            next_tok[row] = tok;
+        }
+    }
+    if (tid == 0 && gap && picked[W].s > NEG * 0.5f) gap[n] = fminf(gap[n], picked[W - 1].s - picked[W].s);
+}
+
+}  // namespace capdec
+
+using namespace capdec;
+
+extern "C" int capdec_decode_attn(const void* q, int ldq, const void* k, const void* v, int ldkv, void* out, int ldo,
+                                  const int* anc, int R, int H, int dh, int Tmax, int t, int W, int S, float scale,
+                                  capdec_stream_t stream) {
+    CAPDEC_REQUIRE(q && k && v && out, "capdec_decode_attn: null pointer");
+    CAPDEC_REQUIRE(R > 0 && H > 0 && (dh == 32 || dh == 64 || dh == 128), "capdec_decode_attn: bad shape R=%d H=%d dh=%d", R, H, dh);
+    CAPDEC_REQUIRE(anc ? (Tmax > 0 && t >= 0 && t < Tmax) : (S > 0 && W > 0), "capdec_decode_attn: bad cache geometry");
+    CAPDEC_REQUIRE(aligned16(q) && aligned16(k) && aligned16(v) && aligned16(out) && ldq % 4 == 0 && ldkv % 4 == 0 &&
+                       ldo % 4 == 0, "capdec_decode_attn: operands must be 16-byte aligned with strides %% 4 == 0");
+    DecodeAttnParams p;
+    p.q = (const float*)q; p.ldq = ldq; p.k = (const float*)k; p.v = (const float*)v; p.ldkv = ldkv;
+    p.out = (float*)out; p.ldo = ldo; p.anc = anc; p.R = R; p.H = H; p.Tmax = Tmax; p.t = t; p.W = W; p.S = S;
+    p.scale = scale;
+    const dim3 grid((R * H + 3) / 4);
+    hipStream_t st = (hipStream_t)stream;
+    if (dh == 32) hipLaunchKernelGGL(decode_attn_kernel<32>, grid, dim3(256), 0, st, p);
+    else if (dh == 64) hipLaunchKernelGGL(decode_attn_kernel<64>, grid, dim3(256), 0, st, p);
+    else hipLaunchKernelGGL(decode_attn_kernel<128>, grid, dim3(256), 0, st, p);
+    return check_launch("capdec_decode_attn");
+}
+
+extern "C" int capdec_greedy_select(const void* logits, int ldl, int* done, int* seq, int64_t* next_tok, void* gap, int R,
+                                    int V, int Tmax, int t, capdec_stream_t stream) {
+    CAPDEC_REQUIRE(logits && done && seq && next_tok && R > 0 && V > 0 && ldl >= V && t >= 0 && t < Tmax,
+                   "capdec_greedy_select: bad arguments");
+    hipLaunchKernelGGL(greedy_select_kernel, dim3(R), dim3(256), 0, (hipStream_t)stream, (const float*)logits, ldl, done,
+                       seq, next_tok, (float*)gap, V, Tmax, t);
+    return check_launch("capdec_greedy_select");
+}
+
+extern "C" int capdec_beam_select(const void* logits, int ldl, const void* score_in, void* score_out, const int* fin_in,
+                                  int* fin_out, const int* anc_in, int* anc_out, const int* seq_in, int* seq_out,
+                                  int64_t* next_tok, void* gap, int N, int W, int V, int Tmax, int t,
+                                  capdec_stream_t stream) {
+    CAPDEC_REQUIRE(logits && score_in && score_out && fin_in && fin_out && anc_in && anc_out && seq_in && seq_out &&
+                       next_tok, "capdec_beam_select: null pointer");
+    CAPDEC_REQUIRE(N > 0 && W >= 1 && W <= MAXW && V >= W + 1 && ldl >= V && t >= 0 && t < Tmax,
+                   "capdec_beam_select: bad shape N=%d W=%d (max %d) V=%d t=%d Tmax=%d", N, W, MAXW, V, t, Tmax);
+    CAPDEC_REQUIRE((uint64_t)W * V < (1ull << 31), "capdec_beam_select: W*V too large");
+    hipLaunchKernelGGL(beam_select_kernel, dim3(N), dim3(256), 0, (hipStream_t)stream, (const float*)logits, ldl,
+                       (const float*)score_in, (float*)score_out, fin_in, fin_out, anc_in, anc_out, seq_in, seq_out,
+                       next_tok, (float*)gap, W, V, Tmax, t);
+    return check_launch("capdec_beam_select");
+}

@@ -145,6 +145,31 @@ int capdec_clip_scale(void* g, size_t n, const void* gnorm_sq, float max_norm, c
 int capdec_adamw(void* p, const void* g, void* m, void* v, size_t n, float lr, float beta1, float beta2, float eps,
                  float weight_decay, int step, const void* gnorm_sq, float max_norm, capdec_stream_t stream);
 
+/* ---- KV-cached decode step: greedy / beam search (NEW capability: the reference only samples,
+ * ref train.py:338-368, and re-runs the whole prefix every step, train.py:312-332) ----------------
+ * capdec_decode_attn: single-query attention of every row r (R = images * W beams) against
+ *   - self (anc != NULL): keys j = 0..t of the cache; position j of row r lives in cache row
+ *     (slot*Tmax + j), slot = (j == t ? r : anc[r*Tmax + j]); k / v point at the K and V halves of the
+ *     cache, row stride ldkv;
+ *   - cross (anc == NULL): keys j = 0..S-1 of image r / W: row ((r/W)*S + j) of k / v.
+ * capdec_greedy_select: seq[r, t] = next_tok[r] = done[r] ? PAD : argmax_v logits[r, v] (ties -> lowest id);
+ *   done[r] |= (token == END); gap[r] = min(gap[r], top1 - top2) on live rows (gap may be NULL).
+ * capdec_beam_select (the beam top-k / reorder kernel), per image n with W <= 8 beams: rank the W*V
+ *   candidates score[w] + log_softmax(logits[w])[v] by (score desc, w*V+v asc); a finished beam
+ *   proposes only (PAD, score unchanged).  Writes the W winners' score / finished flag / next token
+ *   and REORDERS the hypothesis state by rewriting the int tables only: seq_out[row, 0..t] and the
+ *   ancestry table anc_out[row, 0..t] (the K/V cache itself is never moved).  gap[n] = min margin
+ *   between the last kept and first rejected candidate (may be NULL).
+ */
+int capdec_decode_attn(const void* q, int ldq, const void* k, const void* v, int ldkv, void* out, int ldo,
+                       const int* anc, int R, int H, int dh, int Tmax, int t, int W, int S, float scale,
+                       capdec_stream_t stream);
+int capdec_greedy_select(const void* logits, int ldl, int* done, int* seq, int64_t* next_tok, void* gap, int R, int V,
+                         int Tmax, int t, capdec_stream_t stream);
+int capdec_beam_select(const void* logits, int ldl, const void* score_in, void* score_out, const int* fin_in,
+                       int* fin_out, const int* anc_in, int* anc_out, const int* seq_in, int* seq_out,
+                       int64_t* next_tok, void* gap, int N, int W, int V, int Tmax, int t, capdec_stream_t stream);
+
 /* ---- elementwise helpers for the sub-module-at-a-time call path ---------------------------------
  * capdec_pe_add: out[r,:] = dropout(x[r,:] + pe[t0 + (r/div)%mod, :]) over x viewed as [R,d]
  *   (seq-first [T,B,d]: div=B, mod=T -- PositionalEncoding.forward, ref models.py:17-19).

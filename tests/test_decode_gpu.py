@@ -1,0 +1,93 @@
+"""KV-cached greedy / beam decode (HIP) against the CPU oracle's full-prefix-recompute definitions.
+
+Token ids must be bit-exact (north_star).  fp32 reduction orders differ between CPU and GPU, so an
+argmax / top-k near-tie could legitimately flip; the goldens record the minimum top-1/top-2 margin
+(>= 8e-4 here, four orders above the fp32 noise of these logits) so exact equality is a fair bar.
+"""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from conftest import GOLDEN
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda"
+TINY = dict(vocab_size=50, d_model=64, nhead=2, num_decoder_layers=2, feature_dim=24)
+
+
+def _tiny_model():
+    from imagecaption_amd import ImageCaptioningModel
+    w = np.load(os.path.join(GOLDEN, "tiny_weights.npz"))
+    model = ImageCaptioningModel(**TINY)
+    model.load_state_dict({k: torch.from_numpy(w[k]) for k in w.files}, strict=False)
+    with torch.no_grad():
+        model.output_layer[3].weight.mul_(8.0)  # as oracle/gen_golden.py:gen_decode
+    return model.to(DEV).eval()
+
+
+@pytest.mark.parametrize("S", [1, 5])
+def test_greedy_and_beam_match_golden_ids(S):
+    from imagecaption_amd.decode import CaptionDecoder
+    g = np.load(os.path.join(GOLDEN, "decode_tiny.npz"))
+    dec = CaptionDecoder(_tiny_model())
+    feats = torch.from_numpy(g[f"S{S}/features"]).to(DEV)
+    ids, gap = dec.greedy(feats, max_len=20, return_gap=True)
+    assert np.array_equal(ids.cpu().numpy(), g[f"S{S}/greedy_ids"])
+    assert abs(gap.min().item() - float(g[f"S{S}/greedy_min_gap"])) < 1e-3
+    for W in (3, 5):
+        ids, scores, gap = dec.beam(feats, beam=W, max_len=20, return_gap=True)
+        assert np.array_equal(ids.cpu().numpy(), g[f"S{S}/beam{W}_ids"]), W
+        assert np.abs(scores.cpu().numpy() - g[f"S{S}/beam{W}_scores"]).max() < 2e-4
+        assert abs(gap.min().item() - float(g[f"S{S}/beam{W}_min_gap"])) < 1e-3
+    # determinism and beam-1 == greedy
+    a, _ = dec.beam(feats, beam=3, max_len=20)
+    b, _ = dec.beam(feats, beam=3, max_len=20)
+    assert torch.equal(a, b)
+    b1, _ = dec.beam(feats, beam=1, max_len=20)
+    assert torch.equal(b1[:, 0], dec.greedy(feats, max_len=20))
+
+
+def test_decode_matches_live_oracle_dh64_longer_memory():
+    from imagecaption_amd import ImageCaptioningModel
+    from imagecaption_amd.decode import CaptionDecoder
+    from oracle.torch_oracle import OracleCaptionDecoder, beam_decode, greedy_decode
+    cfg = dict(vocab_size=300, d_model=128, nhead=2, num_decoder_layers=2, feature_dim=40)
+    torch.manual_seed(7)
+    ref = OracleCaptionDecoder(**cfg).eval()
+    with torch.no_grad():
+        ref.output_layer[3].weight.mul_(6.0)
+    model = ImageCaptioningModel(**cfg)
+    model.load_state_dict(ref.state_dict())
+    dec = CaptionDecoder(model.to(DEV))
+    feats = torch.randn(6, 9, 40, generator=torch.Generator().manual_seed(3))
+    ids_ref, gap = greedy_decode(ref, feats, max_len=24)
+    ids = dec.greedy(feats.to(DEV), max_len=24)
+    if gap > 1e-4:
+        assert torch.equal(ids.cpu(), ids_ref)
+    bids_ref, sc_ref, bgap = beam_decode(ref, feats, beam=4, max_len=24)
+    bids, sc = dec.beam(feats.to(DEV), beam=4, max_len=24)
+    if bgap > 1e-4:
+        assert torch.equal(bids.cpu(), bids_ref)
+        assert (sc.cpu() - sc_ref).abs().max() < 3e-4
+    assert gap > 1e-4 or bgap > 1e-4, "both margins degenerate: pick another seed"
+
+
+def test_kv_cached_step_logits_equal_full_prefix_forward():
+    """Step t of the cached engine must give the last-position logits of model.forward on the prefix."""
+    from imagecaption_amd.decode import CaptionDecoder
+    model = _tiny_model()
+    dec = CaptionDecoder(model)
+    g = torch.Generator().manual_seed(11)
+    feats = torch.randn(4, 5, 24, generator=g).to(DEV)
+    toks = torch.randint(5, 50, (4, 9), generator=g).to(DEV)
+    toks[:, 0] = 1
+    st = dec._prepare(feats, 1, 9)
+    mask = model.generate_square_subsequent_mask(9).to(DEV)
+    with torch.no_grad():
+        full = model(feats, toks, mask)
+        for t in range(9):
+            step = dec._step(toks[:, t].contiguous(), t, st)
+            err = (step - full[:, t]).abs().max() / full[:, t].abs().max()
+            assert err < 2e-5, (t, float(err))

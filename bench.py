@@ -150,9 +150,16 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    # rehearsal hooks (tests only): CAPDEC_DIST_BACKEND=gloo + CAPDEC_SINGLE_DEVICE=1 run N ranks on one GPU
+    backend = os.environ.get("CAPDEC_DIST_BACKEND", "nccl")
+    if os.environ.get("CAPDEC_SINGLE_DEVICE") == "1":
+        local_rank = 0
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
+        if backend == "nccl":
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
+        else:
+            dist.init_process_group(backend, rank=rank, world_size=world)
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X: the capdec ops have no CPU fallback")
     torch.cuda.set_device(local_rank)
@@ -190,11 +197,12 @@ def main():
     decode = None if args.no_decode else decode_bench(model, cfg, dev, rank, world, images=args.decode_images,
                                                       max_len=min(cfg["T"], 20))
 
+    # the instrumented step contains the gradient all-reduce: every rank must run it
+    agg, detail = profile_step(trainer, feats, ids)
     out = None
     if rank == 0:
         ms = dt / args.steps * 1e3
         value = cfg["batch"] * world * args.steps / dt
-        agg, detail = profile_step(trainer, feats, ids)
         gemm_flops = sum(a[1] for k, a in agg.items() if k.startswith("gemm"))
         gemm_time = sum(a[3] for k, a in agg.items() if k.startswith("gemm"))
         gemm_n = sum(a[0] for k, a in agg.items() if k.startswith("gemm"))

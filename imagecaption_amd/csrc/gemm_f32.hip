@@ -102,7 +102,40 @@ __global__ __launch_bounds__(256) void gemm_f32_kernel(GemmParams p) {
     const int nk = (kend - kbeg + GBK - 1) / GBK;
 
     float4 ra[A_V4], rb[B_V4];
-    auto gload = [&](int k0) {
+    // Interior workgroups (whole tile in bounds, aligned, K range a multiple of the k-tile) stream
+    // their operands through pre-computed per-thread pointers: one global_load_dwordx4 + one pointer
+    // bump per float4, no bounds logic in the loop (the guarded loader's branches cost as many issue
+    // slots as the MFMAs themselves at 4-5 waves per SIMD).
+    const bool interior = VEC && (m0 + BM <= p.M) && (n0 + BN <= p.N) && ((kend - kbeg) % GBK == 0);
+    const float* pa[A_V4];
+    const float* pb[B_V4];
+#pragma unroll
+    for (int i = 0; i < A_V4; ++i) {
+        const int f = tid + i * NT;
+        if (AK) pa[i] = p.A + (size_t)(m0 + f / (GBK / 4)) * p.lda + kbeg + (f % (GBK / 4)) * 4;
+        else pa[i] = p.A + (size_t)(kbeg + f / (BM / 4)) * p.lda + m0 + (f % (BM / 4)) * 4;
+    }
+#pragma unroll
+    for (int i = 0; i < B_V4; ++i) {
+        const int f = tid + i * NT;
+        if (BKM) pb[i] = p.B + (size_t)(n0 + f / (GBK / 4)) * p.ldb + kbeg + (f % (GBK / 4)) * 4;
+        else pb[i] = p.B + (size_t)(kbeg + f / (BN / 4)) * p.ldb + n0 + (f % (BN / 4)) * 4;
+    }
+    const size_t step_a = AK ? (size_t)GBK : (size_t)GBK * p.lda;
+    const size_t step_b = BKM ? (size_t)GBK : (size_t)GBK * p.ldb;
+    auto gload_fast = [&]() {
+#pragma unroll
+        for (int i = 0; i < A_V4; ++i) {
+            ra[i] = *reinterpret_cast<const float4*>(pa[i]);
+            pa[i] += step_a;
+        }
+#pragma unroll
+        for (int i = 0; i < B_V4; ++i) {
+            rb[i] = *reinterpret_cast<const float4*>(pb[i]);
+            pb[i] += step_b;
+        }
+    };
+    auto gload_guarded = [&](int k0) {
 #pragma unroll
         for (int i = 0; i < A_V4; ++i) {
             const int f = tid + i * NT;
@@ -129,6 +162,10 @@ __global__ __launch_bounds__(256) void gemm_f32_kernel(GemmParams p) {
                 rb[i] = load4<VEC>(p.B + (size_t)gk * p.ldb + gn, gk < kend, p.N - gn);
             }
         }
+    };
+    auto gload = [&](int k0) {
+        if (interior) gload_fast();
+        else gload_guarded(k0);
     };
     auto lstore = [&](int buf) {
         float* As = smem + buf * (A_SZ + B_SZ);

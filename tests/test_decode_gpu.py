@@ -91,3 +91,36 @@ def test_kv_cached_step_logits_equal_full_prefix_forward():
             step = dec._step(toks[:, t].contiguous(), t, st)
             err = (step - full[:, t]).abs().max() / full[:, t].abs().max()
             assert err < 2e-5, (t, float(err))
+
+
+def test_bleu4_gate_reference_shape_greedy_vs_oracle():
+    """north_star gate: BLEU-4 on test captions within 0.1 (BLEU points) of the oracle with the same
+    weights.  Reference shape (d=512, 8 heads, 6 layers, V=108, S=1), 24 real test captions as references,
+    synthetic 768-d features, random-init weights (no checkpoint ships), greedy length 24."""
+    import json
+    from imagecaption_amd import ImageCaptioningModel
+    from imagecaption_amd.bleu import bleu_1_4
+    from imagecaption_amd.decode import CaptionDecoder
+    from oracle.torch_oracle import OracleCaptionDecoder, greedy_decode
+    torch.manual_seed(42)
+    ref = OracleCaptionDecoder(vocab_size=108, d_model=512, nhead=8, num_decoder_layers=6, feature_dim=768).eval()
+    with torch.no_grad():
+        ref.output_layer[3].weight.mul_(4.0)
+    model = ImageCaptioningModel(108)
+    model.load_state_dict(ref.state_dict())
+    dec = CaptionDecoder(model.to(DEV))
+    n, T = 24, 24
+    feats = torch.randn(n, 768, generator=torch.Generator().manual_seed(5))
+    caps = np.load(os.path.join(GOLDEN, "captions_test.npz"))
+    ends = np.cumsum(caps["lengths"].astype(np.int64))
+    refs = [caps["tokens"][ends[i] - caps["lengths"][i]:ends[i]].tolist() for i in range(n)]
+    with open(os.path.join(GOLDEN, "vocab.json")) as f:
+        idx2word = dict(enumerate(json.load(f)))
+    torch.set_num_threads(min(16, os.cpu_count() or 1))
+    ids_ref, gap = greedy_decode(ref, feats, max_len=T)
+    ids = dec.greedy(feats.to(DEV), max_len=T).cpu()
+    b_ref = bleu_1_4(refs, ids_ref.tolist(), idx2word)
+    b_hip = bleu_1_4(refs, ids.tolist(), idx2word)
+    assert abs(100 * b_hip[1] - 100 * b_ref[1]) <= 0.1 and abs(100 * b_hip[0] - 100 * b_ref[0]) <= 0.1
+    if gap > 1e-4:
+        assert torch.equal(ids, ids_ref)

@@ -32,31 +32,40 @@ struct AttnParams {
 
 __device__ __forceinline__ int row_of(int r, int half) { return (r & 3) + 8 * (r >> 2) + 4 * half; }
 
+// A 32 x DH tile moves global -> registers (coalesced: 16 consecutive lanes read one 256-B row
+// piece) -> LDS, in two separate steps so the global loads of the NEXT tile can be in flight
+// while the current one is being multiplied (register prefetch, no extra LDS).
 template <int DH>
-__device__ __forceinline__ void load_tile(float* s, const float* g, int ldg, int row0, int T, float mul, int lane) {
-    constexpr int LD = DH + 4;
+__device__ __forceinline__ void tile_gload(float4* regs, const float* g, int ldg, int row0, int T, int lane) {
 #pragma unroll
     for (int i = 0; i < DH / 8; ++i) {
         const int f = lane + 64 * i;
         const int row = f / (DH / 4), c4 = f % (DH / 4);
         const int t = row0 + row;
-        float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-        if (t < T) v = *reinterpret_cast<const float4*>(g + (size_t)t * ldg + c4 * 4);
+        regs[i] = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (t < T) regs[i] = *reinterpret_cast<const float4*>(g + (size_t)t * ldg + c4 * 4);
+    }
+}
+template <int DH>
+__device__ __forceinline__ void tile_lstore(float* s, const float4* regs, float mul, int lane) {
+    constexpr int LD = DH + 4;
+#pragma unroll
+    for (int i = 0; i < DH / 8; ++i) {
+        const int f = lane + 64 * i;
+        const int row = f / (DH / 4), c4 = f % (DH / 4);
+        float4 v = regs[i];
         v.x *= mul; v.y *= mul; v.z *= mul; v.w *= mul;
         *reinterpret_cast<float4*>(&s[row * LD + c4 * 4]) = v;
     }
 }
-
-// fragment of the "row on lane" operand: row = lane&31, k = 8*jj + 4*half + c
+// fragment of the "row on lane" MFMA operand from an LDS image: row = lane&31, k = 8*jj + 4*half + c.
+// (Fragment-shaped loads straight from global touch 32 lines per instruction; staging the tile
+// through LDS in full rows first is the cheaper path on this chip.)
 template <int DH>
-__device__ __forceinline__ void load_frag_global(float4* f, const float* g, int ldg, int row, int T, float mul, int half) {
+__device__ __forceinline__ void lds_frag(float4* f, const float* s, int l31, int half) {
+    constexpr int LD = DH + 4;
 #pragma unroll
-    for (int jj = 0; jj < DH / 8; ++jj) {
-        float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-        if (row < T) v = *reinterpret_cast<const float4*>(g + (size_t)row * ldg + 8 * jj + 4 * half);
-        v.x *= mul; v.y *= mul; v.z *= mul; v.w *= mul;
-        f[jj] = v;
-    }
+    for (int jj = 0; jj < DH / 8; ++jj) f[jj] = *reinterpret_cast<const float4*>(&s[l31 * LD + 8 * jj + 4 * half]);
 }
 
 // acc += A(lds rows on lanes) * B(register fragment)^T  over the head dimension
@@ -134,24 +143,35 @@ __global__ __launch_bounds__(64) void attn_fwd_kernel(AttnParams p) {
     const float* kg = p.k + (size_t)b * p.Tk * p.ldk + h * DH;
     const float* vg = p.v + (size_t)b * p.Tk * p.ldv + h * DH;
 
-    float4 qf[DH / 8];
-    load_frag_global<DH>(qf, qg, p.ldq, q0 + l31, p.Tq, p.scale, half);
+    float4 qf[DH / 8], kr[DH / 8], vr[DH / 8];
+    const int query = q0 + l31;
+    int kmax = p.Tk;
+    if (p.causal) kmax = min(p.Tk, q0 + 31 + off + 1);
+    const int nkt = kmax > 0 ? (kmax + 31) / 32 : 0;
+    tile_gload<DH>(qf, qg, p.ldq, q0, p.Tq, lane);
+    if (nkt > 0) {
+        tile_gload<DH>(kr, kg, p.ldk, 0, p.Tk, lane);
+        tile_gload<DH>(vr, vg, p.ldv, 0, p.Tk, lane);
+    }
+    tile_lstore<DH>(Ks, qf, p.scale, lane);
+    __syncthreads();
+    lds_frag<DH>(qf, Ks, l31, half);
     f32x16 oacc[DH / 32];
 #pragma unroll
     for (int dt = 0; dt < DH / 32; ++dt)
 #pragma unroll
         for (int r = 0; r < 16; ++r) oacc[dt][r] = 0.f;
     float m_run = -INFINITY, l_run = 0.f;
-    const int query = q0 + l31;
-    int kmax = p.Tk;
-    if (p.causal) kmax = min(p.Tk, q0 + 31 + off + 1);
-    const int nkt = kmax > 0 ? (kmax + 31) / 32 : 0;
     for (int kt = 0; kt < nkt; ++kt) {
         const int k0 = kt * 32;
         __syncthreads();
-        load_tile<DH>(Ks, kg, p.ldk, k0, p.Tk, 1.f, lane);
-        load_tile<DH>(Vs, vg, p.ldv, k0, p.Tk, 1.f, lane);
+        tile_lstore<DH>(Ks, kr, 1.f, lane);
+        tile_lstore<DH>(Vs, vr, 1.f, lane);
         __syncthreads();
+        if (kt + 1 < nkt) {  // next tile's loads fly while this one is multiplied
+            tile_gload<DH>(kr, kg, p.ldk, k0 + 32, p.Tk, lane);
+            tile_gload<DH>(vr, vg, p.ldv, k0 + 32, p.Tk, lane);
+        }
         f32x16 s = mma_lds_reg<DH>(Ks, qf, l31, half);
         float mloc = -INFINITY;
 #pragma unroll
@@ -222,35 +242,51 @@ __global__ __launch_bounds__(64) void attn_bwd_dq_kernel(AttnParams p) {
     const float* og = p.o + (size_t)b * p.Tq * p.ldo + h * DH;
     const float* dog = p.dout + (size_t)b * p.Tq * p.lddo + h * DH;
 
-    float4 qf[DH / 8], dof[DH / 8];
-    load_frag_global<DH>(qf, qg, p.ldq, query, p.Tq, p.scale, half);
-    load_frag_global<DH>(dof, dog, p.lddo, query, p.Tq, 1.f, half);
+    float4 qf[DH / 8], dof[DH / 8], kr[DH / 8], vr[DH / 8];
+    int kmax = p.Tk;
+    if (p.causal) kmax = min(p.Tk, q0 + 31 + off + 1);
+    const int nkt = kmax > 0 ? (kmax + 31) / 32 : 0;
+    // Q, dO and O tiles arrive in full rows and are re-read as MFMA fragments from LDS
+    tile_gload<DH>(qf, qg, p.ldq, q0, p.Tq, lane);
+    tile_gload<DH>(dof, dog, p.lddo, q0, p.Tq, lane);
+    tile_gload<DH>(kr, og, p.ldo, q0, p.Tq, lane);  // O (kr is free until the key loop)
+    tile_lstore<DH>(Ks, qf, p.scale, lane);
+    tile_lstore<DH>(Vs, dof, 1.f, lane);
+    __syncthreads();
+    lds_frag<DH>(qf, Ks, l31, half);
+    lds_frag<DH>(dof, Vs, l31, half);
+    __syncthreads();
+    tile_lstore<DH>(Ks, kr, 1.f, lane);
+    __syncthreads();
     float dsum = 0.f;
-    if (query < p.Tq) {
 #pragma unroll
-        for (int jj = 0; jj < DH / 8; ++jj) {
-            const float4 ov = *reinterpret_cast<const float4*>(og + (size_t)query * p.ldo + 8 * jj + 4 * half);
-            dsum += (dof[jj].x * ov.x + dof[jj].y * ov.y) + (dof[jj].z * ov.z + dof[jj].w * ov.w);
-        }
+    for (int jj = 0; jj < DH / 8; ++jj) {
+        const float4 ov = *reinterpret_cast<const float4*>(&Ks[l31 * LD + 8 * jj + 4 * half]);
+        dsum += (dof[jj].x * ov.x + dof[jj].y * ov.y) + (dof[jj].z * ov.z + dof[jj].w * ov.w);
     }
     dsum += __shfl_xor(dsum, 32, 64);
     const float lse = query < p.Tq ? p.lse[(size_t)bh * p.Tq + query] : INFINITY;
     if (lane < 32 && query < p.Tq) p.delta[(size_t)bh * p.Tq + query] = dsum;
+    if (nkt > 0) {
+        tile_gload<DH>(kr, kg, p.ldk, 0, p.Tk, lane);
+        tile_gload<DH>(vr, vg, p.ldv, 0, p.Tk, lane);
+    }
 
     f32x16 dqacc[DH / 32];
 #pragma unroll
     for (int dt = 0; dt < DH / 32; ++dt)
 #pragma unroll
         for (int r = 0; r < 16; ++r) dqacc[dt][r] = 0.f;
-    int kmax = p.Tk;
-    if (p.causal) kmax = min(p.Tk, q0 + 31 + off + 1);
-    const int nkt = kmax > 0 ? (kmax + 31) / 32 : 0;
     for (int kt = 0; kt < nkt; ++kt) {
         const int k0 = kt * 32;
         __syncthreads();
-        load_tile<DH>(Ks, kg, p.ldk, k0, p.Tk, 1.f, lane);
-        load_tile<DH>(Vs, vg, p.ldv, k0, p.Tk, 1.f, lane);
+        tile_lstore<DH>(Ks, kr, 1.f, lane);
+        tile_lstore<DH>(Vs, vr, 1.f, lane);
         __syncthreads();
+        if (kt + 1 < nkt) {
+            tile_gload<DH>(kr, kg, p.ldk, k0 + 32, p.Tk, lane);
+            tile_gload<DH>(vr, vg, p.ldv, k0 + 32, p.Tk, lane);
+        }
         f32x16 s = mma_lds_reg<DH>(Ks, qf, l31, half);    // S^T[key][query]
         f32x16 dp = mma_lds_reg<DH>(Vs, dof, l31, half);  // dP^T[key][query]
         float ds[16];
@@ -296,9 +332,15 @@ __global__ __launch_bounds__(64) void attn_bwd_dkv_kernel(AttnParams p) {
     const float* vg = p.v + (size_t)b * p.Tk * p.ldv + h * DH;
     const float* dog = p.dout + (size_t)b * p.Tq * p.lddo + h * DH;
 
-    float4 kf[DH / 8], vf[DH / 8];
-    load_frag_global<DH>(kf, kg, p.ldk, key, p.Tk, 1.f, half);
-    load_frag_global<DH>(vf, vg, p.ldv, key, p.Tk, 1.f, half);
+    float4 kf[DH / 8], vf[DH / 8], qr[DH / 8], dr[DH / 8];
+    // this wave's K and V tile: full rows -> LDS -> fragments (kept in registers for the whole q loop)
+    tile_gload<DH>(kf, kg, p.ldk, k0, p.Tk, lane);
+    tile_gload<DH>(vf, vg, p.ldv, k0, p.Tk, lane);
+    tile_lstore<DH>(Qs, kf, 1.f, lane);
+    tile_lstore<DH>(dOs, vf, 1.f, lane);
+    __syncthreads();
+    lds_frag<DH>(kf, Qs, l31, half);
+    lds_frag<DH>(vf, dOs, l31, half);
     f32x16 dkacc[DH / 32], dvacc[DH / 32];
 #pragma unroll
     for (int dt = 0; dt < DH / 32; ++dt)
@@ -311,17 +353,25 @@ __global__ __launch_bounds__(64) void attn_bwd_dkv_kernel(AttnParams p) {
         qstart = qmin > 0 ? (qmin / 32) : 0;
     }
     const int nqt = (p.Tq + 31) / 32;
+    if (qstart < nqt) {
+        tile_gload<DH>(qr, qg, p.ldq, qstart * 32, p.Tq, lane);
+        tile_gload<DH>(dr, dog, p.lddo, qstart * 32, p.Tq, lane);
+    }
     for (int qt = qstart; qt < nqt; ++qt) {
         const int q0 = qt * 32;
         __syncthreads();
-        load_tile<DH>(Qs, qg, p.ldq, q0, p.Tq, p.scale, lane);
-        load_tile<DH>(dOs, dog, p.lddo, q0, p.Tq, 1.f, lane);
+        tile_lstore<DH>(Qs, qr, p.scale, lane);
+        tile_lstore<DH>(dOs, dr, 1.f, lane);
         if (lane < 32) {
             const int qq = q0 + lane;
             lse_s[lane] = qq < p.Tq ? p.lse[(size_t)bh * p.Tq + qq] : INFINITY;
             del_s[lane] = qq < p.Tq ? p.delta[(size_t)bh * p.Tq + qq] : 0.f;
         }
         __syncthreads();
+        if (qt + 1 < nqt) {
+            tile_gload<DH>(qr, qg, p.ldq, q0 + 32, p.Tq, lane);
+            tile_gload<DH>(dr, dog, p.lddo, q0 + 32, p.Tq, lane);
+        }
         f32x16 s = mma_lds_reg<DH>(Qs, kf, l31, half);    // S[query][key]
         f32x16 dp = mma_lds_reg<DH>(dOs, vf, l31, half);  // dP[query][key]
         float pd[16], ds[16];

@@ -280,14 +280,33 @@ __global__ __launch_bounds__(256) void gemm_f32_kernel(GemmParams p) {
         }
 }
 
-__global__ __launch_bounds__(256) void gemm_splitk_reduce_kernel(GemmParams p, int S) {
+__global__ __launch_bounds__(256) void gemm_splitk_reduce_kernel(GemmParams p, int S, int vec) {
     const size_t total = (size_t)p.M * p.N;
     const size_t stride = (size_t)gridDim.x * blockDim.x;
-    for (size_t e = (size_t)blockIdx.x * blockDim.x + threadIdx.x; e < total; e += stride) {
-        float v = 0.f;
-        for (int z = 0; z < S; ++z) v += p.ws[(size_t)z * total + e];
-        const int m = (int)(e / p.N), n = (int)(e % p.N);
-        p.C[(size_t)m * p.ldc + n] = epilogue_apply(p, v, m, n);
+    if (vec) {  // N % 4 == 0: one float4 of every slab per thread, slabs summed in slab order
+        const size_t total4 = total >> 2;
+        for (size_t e4 = (size_t)blockIdx.x * blockDim.x + threadIdx.x; e4 < total4; e4 += stride) {
+            float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll 4
+            for (int z = 0; z < S; ++z) {
+                const float4 t = reinterpret_cast<const float4*>(p.ws + (size_t)z * total)[e4];
+                v.x += t.x; v.y += t.y; v.z += t.z; v.w += t.w;
+            }
+            const size_t e = e4 << 2;
+            const int m = (int)(e / p.N), n = (int)(e % p.N);
+            float* c = p.C + (size_t)m * p.ldc + n;
+            c[0] = epilogue_apply(p, v.x, m, n);
+            c[1] = epilogue_apply(p, v.y, m, n + 1);
+            c[2] = epilogue_apply(p, v.z, m, n + 2);
+            c[3] = epilogue_apply(p, v.w, m, n + 3);
+        }
+    } else {
+        for (size_t e = (size_t)blockIdx.x * blockDim.x + threadIdx.x; e < total; e += stride) {
+            float v = 0.f;
+            for (int z = 0; z < S; ++z) v += p.ws[(size_t)z * total + e];
+            const int m = (int)(e / p.N), n = (int)(e % p.N);
+            p.C[(size_t)m * p.ldc + n] = epilogue_apply(p, v, m, n);
+        }
     }
     if (p.colsum && blockIdx.x == 0) {
         for (int m = threadIdx.x; m < p.M; m += blockDim.x) {
@@ -443,9 +462,11 @@ extern "C" int capdec_gemm(int transA, int transB, int M, int N, int K, const vo
     if (rc) return rc;
     if (pl.split > 1) {
         const size_t total = (size_t)M * N;
-        int blocks = (int)((total + 255) / 256);
+        const int vec4 = (N % 4 == 0) && aligned16(workspace) ? 1 : 0;
+        int blocks = (int)(((vec4 ? total / 4 : total) + 255) / 256);
         if (blocks > 2048) blocks = 2048;
-        hipLaunchKernelGGL(gemm_splitk_reduce_kernel, dim3(blocks), dim3(256), 0, st, p, pl.split);
+        if (blocks < 1) blocks = 1;
+        hipLaunchKernelGGL(gemm_splitk_reduce_kernel, dim3(blocks), dim3(256), 0, st, p, pl.split, vec4);
         rc = check_launch("capdec_gemm(split-K reduce)");
     }
     return rc;

@@ -7,7 +7,7 @@
 
 namespace capdec {
 
-constexpr int LN_MAX_BLOCKS = 256;
+constexpr int LN_MAX_BLOCKS = 512;
 
 template <int NV>
 __global__ __launch_bounds__(256) void ln_fwd_kernel(const float* __restrict__ x, const float* __restrict__ gamma,
@@ -151,16 +151,17 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(const float* __restrict__ d
     }
 }
 
-// 64 columns per block, 4 row groups: each thread sums a strided quarter of the partial rows,
-// then the four are combined in a fixed order (deterministic).
+// 16 columns x 16 row groups per block: each thread sums a strided 1/16 of the partial rows
+// (independent loads), then the 16 are combined in a fixed order (deterministic).
 __global__ __launch_bounds__(256) void ln_bwd_finalize_kernel(const float* __restrict__ part, float* __restrict__ dgamma,
                                                                float* __restrict__ dbeta, int nblk, int d) {
-    __shared__ float sh[2][4][64];
-    const int cl = threadIdx.x & 63, rg = threadIdx.x >> 6;
-    const int c = blockIdx.x * 64 + cl;
+    __shared__ float sh[2][16][17];
+    const int cl = threadIdx.x & 15, rg = threadIdx.x >> 4;
+    const int c = blockIdx.x * 16 + cl;
     float a = 0.f, b = 0.f;
     if (c < d) {
-        for (int k = rg; k < nblk; k += 4) {
+#pragma unroll 4
+        for (int k = rg; k < nblk; k += 16) {
             a += part[((size_t)k * 2 + 0) * d + c];
             b += part[((size_t)k * 2 + 1) * d + c];
         }
@@ -169,8 +170,14 @@ __global__ __launch_bounds__(256) void ln_bwd_finalize_kernel(const float* __res
     sh[1][rg][cl] = b;
     __syncthreads();
     if (rg == 0 && c < d) {
-        dgamma[c] = (sh[0][0][cl] + sh[0][1][cl]) + (sh[0][2][cl] + sh[0][3][cl]);
-        dbeta[c] = (sh[1][0][cl] + sh[1][1][cl]) + (sh[1][2][cl] + sh[1][3][cl]);
+        float x = 0.f, y = 0.f;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            x += sh[0][r][cl];
+            y += sh[1][r][cl];
+        }
+        dgamma[c] = x;
+        dbeta[c] = y;
     }
 }
 
@@ -239,7 +246,7 @@ extern "C" int capdec_layernorm_bwd(const void* dy, const void* x, const void* g
 #undef CALL
     int rc = check_launch("capdec_layernorm_bwd");
     if (rc) return rc;
-    hipLaunchKernelGGL(ln_bwd_finalize_kernel, dim3((d + 63) / 64), dim3(256), 0, st, (const float*)workspace,
+    hipLaunchKernelGGL(ln_bwd_finalize_kernel, dim3((d + 15) / 16), dim3(256), 0, st, (const float*)workspace,
                        (float*)dgamma, (float*)dbeta, nblk, d);
     return check_launch("capdec_layernorm_bwd(finalize)");
 }

@@ -36,6 +36,7 @@ CONFIGS = {
     "tiny": dict(vocab=50, d=64, heads=2, layers=2, din=24, S=5, T=12, batch=8),
 }
 PEAK_F32_MFMA_TFLOPS = 157.3  # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32, 64 FLOP/clk/SIMD
+PEAK_BF16_MFMA_TFLOPS = 2500.0  # dense bf16 MFMA
 PEAK_HBM_GBS = 8000.0
 
 
@@ -79,10 +80,10 @@ def cpu_baseline(cfg, steps=2):
                       f"stock torch.nn fp32 on {threads} host threads, {dt:.2f} s/step"}
 
 
-def decode_bench(model, cfg, dev, rank, world, images=1024, max_len=20):
+def decode_bench(model, cfg, dev, rank, world, dtype="fp32", images=1024, max_len=20):
     """Beam-3 / beam-5 / greedy captions/s, KV-cached engine, images sharded per rank, no collective."""
     from imagecaption_amd.decode import CaptionDecoder
-    dec = CaptionDecoder(model)
+    dec = CaptionDecoder(model, dtype=dtype)
     feats, _ = synth_batch(cfg, images, dev, 100 + rank)
     res = {}
     for name, fn in (("beam3", lambda: dec.beam(feats, beam=3, max_len=max_len)),
@@ -106,6 +107,15 @@ def decode_bench(model, cfg, dev, rank, world, images=1024, max_len=20):
     res["images_per_gpu"], res["max_len"] = images, max_len
     model.train()
     return res
+
+
+def vocab_traffic(config):
+    """HBM-side bytes per launch of the vocab GEMM from the committed PMC passes (profiles/), C2 only."""
+    path = os.path.join(ROOT, "profiles", "r01_vocab_gemm_traffic.json")
+    if config != "c2" or not os.path.exists(path):
+        return None
+    with open(path) as f:
+        return json.load(f)["traffic_bytes"]
 
 
 def profile_step(trainer, feats, ids):
@@ -142,6 +152,8 @@ def main():
     ap.add_argument("--batch", type=int, default=0, help="per-GPU batch (default: the config's)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-dropout", action="store_true", help="eval-mode step (parity runs only; not the metric)")
+    ap.add_argument("--dtype", default="fp32", choices=["fp32", "bf16"],
+                    help="fp32 = reference precision (the headline); bf16 = bf16 MFMA products, fp32 elsewhere")
     ap.add_argument("--no-decode", action="store_true")
     ap.add_argument("--decode-images", type=int, default=1024, help="images per GPU for the decode leg")
     ap.add_argument("--detail", action="store_true", help="print the per-shape kernel table to stderr")
@@ -174,7 +186,7 @@ def main():
     torch.manual_seed(42)
     model = ImageCaptioningModel(cfg["vocab"], cfg["d"], cfg["heads"], cfg["layers"], feature_dim=cfg["din"]).to(dev)
     model.train()
-    trainer = CaptionTrainer(model, dropout=0.0 if args.no_dropout else 0.1, seed=42)
+    trainer = CaptionTrainer(model, dropout=0.0 if args.no_dropout else 0.1, seed=42, dtype=args.dtype)
     feats, ids = synth_batch(cfg, cfg["batch"], dev, rank)
 
     for _ in range(args.warmup):
@@ -194,7 +206,7 @@ def main():
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t.item())
     loss_val = float(loss.item())
-    decode = None if args.no_decode else decode_bench(model, cfg, dev, rank, world, images=args.decode_images,
+    decode = None if args.no_decode else decode_bench(model, cfg, dev, rank, world, dtype=args.dtype, images=args.decode_images,
                                                       max_len=min(cfg["T"], 20))
 
     # the instrumented step contains the gradient all-reduce: every rank must run it
@@ -210,12 +222,13 @@ def main():
         attn = {k: a for k, a in agg.items() if k.startswith("attn")}
         attn_b = sum(a[2] for a in attn.values())
         attn_t = sum(a[3] for a in attn.values())
+        peak = PEAK_F32_MFMA_TFLOPS if args.dtype == "fp32" else PEAK_BF16_MFMA_TFLOPS
         vk = f"gemm_nt_{cfg['batch'] * cfg['T']}x{cfg['vocab']}x{2 * cfg['d']}"
         vocab = detail.get(vk)
         out = {
             "metric": "train_images_per_sec", "value": value, "unit": "images/s", "n_gpus": world,
             "steps": args.steps, "warmup": args.warmup, "ms_per_step": ms, "higher_is_better": True,
-            "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "scaling": "weak", "vs_baseline": None, "dtype": "f32" if args.dtype == "fp32" else "bf16", "data": "synthetic",
             "config": {"workload": f"BASELINE.json configs[1] (C2): 7x7x2048 grid features, hidden {cfg['d']}, "
                                    f"{cfg['layers']} layers, vocab {cfg['vocab']}, len {cfg['T']}, batch "
                                    f"{cfg['batch']}/GPU, teacher-forced train step incl. dropout, clip, AdamW"
@@ -225,13 +238,14 @@ def main():
             "loss": loss_val,
             "decode": decode,
             "step_tflops_algorithmic": train_flops_per_image(cfg) * value / 1e12,
-            "roofline": {"bound": "mfma", "achieved": ach, "peak": PEAK_F32_MFMA_TFLOPS, "unit": "TFLOP/s",
-                         "frac": ach / PEAK_F32_MFMA_TFLOPS, "traffic": None,
-                         "kernel": "gemm_f32_kernel (all launches of one step)", "launches_per_step": gemm_n,
-                         "gemm_ms_per_step": gemm_time * 1e3},
-            "vocab_gemm": ({"tflops": vocab[1] / vocab[3] / 1e12, "ms": vocab[3] * 1e3 / vocab[0],
-                            "frac_of_f32_mfma_peak": vocab[1] / vocab[3] / 1e12 / PEAK_F32_MFMA_TFLOPS}
-                           if vocab else None),
+            "roofline": ({"bound": "mfma", "achieved": vocab[1] / vocab[3] / 1e12, "peak": peak,
+                          "unit": "TFLOP/s", "frac": vocab[1] / vocab[3] / 1e12 / peak,
+                          "traffic": vocab_traffic(args.config) if args.dtype == "fp32" else None,
+                          "kernel": f"gemm_{'f32' if args.dtype == 'fp32' else 'bf16'}_kernel, vocab projection forward {vk[8:]} (one launch per step)",
+                          "ms": vocab[3] * 1e3 / vocab[0]} if vocab else None),
+            "gemm_all": {"bound": "mfma", "achieved": ach, "peak": peak, "unit": "TFLOP/s",
+                         "frac": ach / peak, "launches_per_step": gemm_n,
+                         "ms_per_step": gemm_time * 1e3},
             "attention": {"bound": "hbm", "achieved": attn_b / attn_t / 1e9 if attn_t else 0.0, "peak": PEAK_HBM_GBS,
                           "unit": "GB/s", "frac": (attn_b / attn_t / 1e9 / PEAK_HBM_GBS) if attn_t else 0.0,
                           "ms_per_step": attn_t * 1e3, "launches_per_step": sum(a[0] for a in attn.values())},

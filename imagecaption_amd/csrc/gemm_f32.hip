@@ -10,40 +10,13 @@
 //       hit distinct banks.
 //   row-contiguous operand (reduction index is the storage row): [k][row] -> four ds_read_b32.
 #include "common.h"
+#include "gemm_common.h"
 
 namespace capdec {
 
+GemmForce g_gemm_force = {0, 0, 0, 0};
+
 typedef float f32x16 __attribute__((ext_vector_type(16)));
-
-struct GemmParams {
-    const float* A;
-    const float* B;
-    float* C;
-    int M, N, K, lda, ldb, ldc;
-    const float* bias;
-    const float* addend;
-    float* pre;
-    const float* aux;
-    float* colsum;
-    int ld_addend, act;
-    Dropout drop;
-    int ksplit;       // K elements per z-slice (multiple of 16)
-    float* ws;        // [S][M][N] partial products when gridDim.z > 1
-    float* ws_colsum; // [S][M]
-    int tiles_n;
-};
-
-
-__device__ __forceinline__ float epilogue_apply(const GemmParams& p, float v, int m, int n) {
-    if (p.bias) v += p.bias[n];
-    const size_t o = (size_t)m * p.ldc + n;
-    if (p.pre) p.pre[o] = v;
-    if (p.act == CAPDEC_ACT_GELU) v = gelu_erf(v);
-    else if (p.act == CAPDEC_ACT_GELU_BWD) v *= gelu_erf_grad(p.aux[o]);
-    if (p.drop.on()) v = p.drop.apply(v, (uint32_t)m * (uint32_t)p.N + (uint32_t)n);
-    if (p.addend) v += p.addend[(size_t)m * p.ld_addend + n];
-    return v;
-}
 
 template <bool VEC>
 __device__ __forceinline__ float4 load4(const float* ptr, bool ok, int rem) {
@@ -318,14 +291,6 @@ __global__ __launch_bounds__(256) void gemm_splitk_reduce_kernel(GemmParams p, i
 }
 
 // ---- host side: tile / split-K choice ---------------------------------------------------------
-struct GemmPlan {
-    int bm, bn, bk, split, ksplit;
-};
-
-static inline int cdiv(int a, int b) { return (a + b - 1) / b; }
-
-static int g_force_bm = 0, g_force_bn = 0, g_force_split = 0, g_force_bk = 0;  // tuning hook (capdec_gemm_tune)
-
 // MFMA-bound cost model, calibrated on tools/gemm_sweep.py (profiles/r01_gemm_sweep.txt).  A CU
 // with r co-resident workgroups runs r waves per SIMD; one wave per SIMD cannot cover its own
 // barrier / load stalls, so the matrix pipe's utilisation u(r) rises with r.  Cost = rounds of
@@ -333,11 +298,11 @@ static int g_force_bm = 0, g_force_bn = 0, g_force_split = 0, g_force_bk = 0;  /
 static GemmPlan plan_gemm(int M, int N, int K) {
     static const int cand[4][2] = {{128, 128}, {128, 64}, {64, 128}, {64, 64}};
     static const double util[5] = {0.0, 0.55, 0.80, 0.97, 1.0};
-    const int bk = g_force_bk ? g_force_bk : 16;
-    if (g_force_bm) {
-        int split = g_force_split > 0 ? g_force_split : 1;
+    const int bk = g_gemm_force.bk ? g_gemm_force.bk : 16;
+    if (g_gemm_force.bm) {
+        int split = g_gemm_force.split > 0 ? g_gemm_force.split : 1;
         int ks = cdiv(cdiv(K, split), bk) * bk;
-        return GemmPlan{g_force_bm, g_force_bn, bk, cdiv(K, ks), ks};
+        return GemmPlan{g_gemm_force.bm, g_gemm_force.bn, bk, cdiv(K, ks), ks};
     }
     GemmPlan best{128, 128, bk, 1, K};
     double best_cost = 1e300;
@@ -390,21 +355,22 @@ extern "C" int capdec_gemm_tune(int bm, int bn, int split, int bk) {
     const bool ok = ((bm == 0) || ((bm == 64 || bm == 128) && (bn == 64 || bn == 128) && split >= 1 && split <= 64)) &&
                     (bk == 0 || bk == 16 || bk == 32);
     CAPDEC_REQUIRE(ok, "capdec_gemm_tune: unsupported tile %dx%d split %d bk %d", bm, bn, split, bk);
-    g_force_bm = bm; g_force_bn = bn; g_force_split = split; g_force_bk = bk;
+    g_gemm_force = GemmForce{bm, bn, split, bk};
     return CAPDEC_OK;
 }
 
 extern "C" size_t capdec_gemm_workspace_bytes(int M, int N, int K) {
     if (M <= 0 || N <= 0 || K <= 0) return 0;
-    GemmPlan pl = plan_gemm(M, N, K);
-    if (pl.split <= 1) return 0;
-    return ((size_t)pl.split * M * N + (size_t)pl.split * M) * sizeof(float);
+    const GemmPlan a = plan_gemm(M, N, K), b = plan_gemm_bf16(M, N, K);
+    const int split = a.split > b.split ? a.split : b.split;
+    if (split <= 1) return 0;
+    return ((size_t)split * M * N + (size_t)split * M) * sizeof(float);
 }
 
 extern "C" int capdec_gemm(int transA, int transB, int M, int N, int K, const void* A, int lda, const void* B,
                            int ldb, void* C, int ldc, const capdec_epilogue* ep, int dtype, void* workspace,
                            size_t workspace_bytes, capdec_stream_t stream) {
-    CAPDEC_REQUIRE(dtype == CAPDEC_F32, "capdec_gemm: dtype %d not supported by this entry point", dtype);
+    CAPDEC_REQUIRE(dtype == CAPDEC_F32 || dtype == CAPDEC_BF16, "capdec_gemm: dtype %d not supported", dtype);
     CAPDEC_REQUIRE(M > 0 && N > 0 && K > 0, "capdec_gemm: bad shape M=%d N=%d K=%d", M, N, K);
     CAPDEC_REQUIRE(A && B && C, "capdec_gemm: null operand");
     CAPDEC_REQUIRE(lda >= (transA ? M : K) && ldb >= (transB ? K : N) && ldc >= N,
@@ -431,7 +397,7 @@ extern "C" int capdec_gemm(int transA, int transB, int M, int N, int K, const vo
         CAPDEC_REQUIRE(!ep->addend || ep->ld_addend >= N, "capdec_gemm: ld_addend too small");
         CAPDEC_REQUIRE(ep->drop_p >= 0.f && ep->drop_p < 1.f, "capdec_gemm: drop_p out of range");
     }
-    GemmPlan pl = plan_gemm(M, N, K);
+    GemmPlan pl = dtype == CAPDEC_BF16 ? plan_gemm_bf16(M, N, K) : plan_gemm(M, N, K);
     if (pl.split > 1) {
         const size_t need = ((size_t)pl.split * M * N + (size_t)pl.split * M) * sizeof(float);
         if (!workspace || workspace_bytes < need) {
@@ -447,7 +413,9 @@ extern "C" int capdec_gemm(int transA, int transB, int M, int N, int K, const vo
     const bool AK = !transA, BKM = transB != 0;
     dim3 grid(cdiv(M, pl.bm) * p.tiles_n, 1, pl.split);
     hipStream_t st = (hipStream_t)stream;
-    if (pl.bk == 32) {
+    if (dtype == CAPDEC_BF16) {
+        launch_gemm_bf16(p, pl, AK, BKM, vec, st);
+    } else if (pl.bk == 32) {
         if (pl.bm == 128 && pl.bn == 128) launch_cfg<128, 128, 32>(p, AK, BKM, vec, grid, st);
         else if (pl.bm == 128 && pl.bn == 64) launch_cfg<128, 64, 32>(p, AK, BKM, vec, grid, st);
         else if (pl.bm == 64 && pl.bn == 128) launch_cfg<64, 128, 32>(p, AK, BKM, vec, grid, st);

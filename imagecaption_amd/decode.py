@@ -27,8 +27,9 @@ START = 1
 
 
 class CaptionDecoder:
-    def __init__(self, model):
+    def __init__(self, model, dtype="fp32"):
         self.model = model.eval()
+        self.dtype = dtype
         dec = model.transformer_decoder
         self.H, self.L = dec.nhead, len(dec.layers)
         self.layers = [layer.param_dict() for layer in dec.layers]
@@ -80,11 +81,12 @@ class CaptionDecoder:
         dev = features.device
         N = features.shape[0]
         S = 1 if features.dim() == 2 else features.shape[1]
-        mem = engine.proj_fwd(self.proj, features.reshape(N * S, -1), self.dp, None)  # [N*S, d]
         cross = []
-        for P in self.layers:
-            wc, bc = P["multihead_attn.in_proj_weight"], P["multihead_attn.in_proj_bias"]
-            cross.append(ops.linear_fwd(mem, wc[d:], bc[d:]))
+        with ops.compute_dtype(self.dtype):
+            mem = engine.proj_fwd(self.proj, features.reshape(N * S, -1), self.dp, None)  # [N*S, d]
+            for P in self.layers:
+                wc, bc = P["multihead_attn.in_proj_weight"], P["multihead_attn.in_proj_bias"]
+                cross.append(ops.linear_fwd(mem, wc[d:], bc[d:]))
         R = N * W
         st = dict(N=N, W=W, R=R, S=S, Tmax=Tmax, cross_kv=cross, cur=0,
                   cache=[torch.empty((R, Tmax, 2 * d), dtype=torch.float32, device=dev) for _ in self.layers],
@@ -103,7 +105,8 @@ class CaptionDecoder:
         gap = torch.full((R,), float("inf"), dtype=torch.float32, device=dev)
         l = lib()
         for t in range(max_len):
-            logits = self._step(tok, t, st)
+            with ops.compute_dtype(self.dtype):
+                logits = self._step(tok, t, st)
             check(l.capdec_greedy_select(ptr(logits), logits.stride(0), ptr(done), ptr(st["seq"][0]), ptr(tok), ptr(gap),
                                          R, self.V, max_len, t, stream()), "capdec_greedy_select")
         ids = st["seq"][0].to(torch.int64)
@@ -123,7 +126,8 @@ class CaptionDecoder:
         cur = 0
         for t in range(max_len):
             st["cur"] = cur
-            logits = self._step(tok, t, st)
+            with ops.compute_dtype(self.dtype):
+                logits = self._step(tok, t, st)
             nxt = cur ^ 1
             check(l.capdec_beam_select(ptr(logits), logits.stride(0), ptr(score[cur]), ptr(score[nxt]), ptr(fin[cur]),
                                        ptr(fin[nxt]), ptr(st["anc"][cur]), ptr(st["anc"][nxt]), ptr(st["seq"][cur]),

@@ -11,9 +11,30 @@ import torch
 from . import _capi
 from ._capi import ACT_GELU, ACT_GELU_BWD, ACT_NONE, F32, check, lib, ptr, stream
 
-__all__ = ["gemm", "linear_fwd", "linear_dgrad", "linear_wgrad", "layernorm_fwd", "layernorm_bwd", "embed_fwd",
+__all__ = ["compute_dtype", "gemm", "linear_fwd", "linear_dgrad", "linear_wgrad", "layernorm_fwd", "layernorm_bwd", "embed_fwd",
            "embed_bwd", "attn_fwd", "attn_bwd", "softmax_ce", "reduce_sum", "sumsq", "adamw", "clip_scale", "pe_add",
            "act_dropout_bwd"]
+
+
+# Arithmetic type of the matrix products.  F32: exact fp32 MFMA (reference precision, the default).
+# BF16: operands rounded to bf16 on load, bf16 MFMA, fp32 accumulation / epilogue / storage
+# ("autocast"-style mixed precision; tolerances are stated separately in the tests).
+COMPUTE_DTYPE = F32
+
+
+class compute_dtype:
+    """with ops.compute_dtype("bf16"): ...  -- scoped override of COMPUTE_DTYPE."""
+
+    def __init__(self, name):
+        self.value = {"f32": F32, "fp32": F32, "bf16": _capi.BF16}[str(name).lower()]
+
+    def __enter__(self):
+        global COMPUTE_DTYPE
+        self.prev, COMPUTE_DTYPE = COMPUTE_DTYPE, self.value
+
+    def __exit__(self, *a):
+        global COMPUTE_DTYPE
+        COMPUTE_DTYPE = self.prev
 
 
 # Optional per-launch timing (bench.py): when PROFILE is a list, GEMM / attention launches are
@@ -83,7 +104,7 @@ def gemm(a, b, trans_a, trans_b, out=None, bias=None, addend=None, pre=None, aux
     ws = _capi.workspace(need, a.device) if need else None
     with _Timed(f"gemm_{'t' if trans_a else 'n'}{'t' if trans_b else 'n'}_{M}x{N}x{K}", 2.0 * M * N * K):
         check(l.capdec_gemm(int(trans_a), int(trans_b), M, N, K, ptr(a), a.stride(0), ptr(b), b.stride(0), ptr(out),
-                            out.stride(0), C.byref(ep), F32, ptr(ws), ws.numel() if ws is not None else 0, stream()),
+                            out.stride(0), C.byref(ep), COMPUTE_DTYPE, ptr(ws), ws.numel() if ws is not None else 0, stream()),
               "capdec_gemm")
     return out
 

@@ -26,11 +26,12 @@ from .parallel import BucketReducer, FlatParams, decoder_param_groups
 
 class CaptionTrainer:
     def __init__(self, model, lr=1e-3, betas=(0.9, 0.999), eps=1e-8, weight_decay=0.01, max_norm=1.0,
-                 smooth_factor=0.1, dropout=0.1, seed=0, process_group=None, overlap=True):
+                 smooth_factor=0.1, dropout=0.1, seed=0, process_group=None, overlap=True, dtype="fp32"):
         self.model = model
         self.lr, self.betas, self.eps, self.wd = lr, betas, eps, weight_decay
         self.max_norm, self.smooth, self.p, self.seed = max_norm, smooth_factor, dropout, seed
         self.pg = process_group
+        self.dtype = dtype  # "fp32" (reference precision) or "bf16" (bf16 MFMA products, fp32 everything else)
         self.world = dist.get_world_size(process_group) if (dist.is_available() and dist.is_initialized()) else 1
         self.step_count = 0
         dec = model.transformer_decoder
@@ -65,6 +66,10 @@ class CaptionTrainer:
 
     # ---- one iteration of ref train.py:24-61 ---------------------------------------------------------
     def forward_backward(self, features, captions, train=True, keep_logits=False):
+        with ops.compute_dtype(self.dtype):
+            return self._forward_backward(features, captions, train, keep_logits)
+
+    def _forward_backward(self, features, captions, train, keep_logits):
         m = self.model
         tgt_in = captions[:, :-1].contiguous()   # ref train.py:29
         tgt_out = captions[:, 1:].contiguous()   # ref train.py:30

@@ -315,3 +315,46 @@ def test_sumsq_and_adamw_against_torch_optim():
     ops.clip_scale(gd, ops.sumsq(gd), 1.0)
     ref = grads[0] * min(1.0, 1.0 / (grads[0].norm().item() + 1e-6))
     assert relerr(gd, ref) < 1e-6
+
+
+# ---------------------------------------------------------------------------------------------
+# bf16-compute mode (operands rounded to bf16, fp32 accumulate): checked against the exact product
+# of the bf16-ROUNDED operands, so the bar is fp32-accumulation noise, not bf16 quantisation.
+@pytest.mark.parametrize("M,N,K", [(3, 50, 24), (129, 257, 100), (256, 512, 512), (300, 1000, 130), (5120, 128, 64),
+                                    (64, 64, 2048), (70, 70, 5120), (33, 27, 21)])
+@pytest.mark.parametrize("ta,tb", [(0, 1), (0, 0), (1, 0), (1, 1)])
+def test_gemm_bf16_compute(M, N, K, ta, tb):
+    ops = _ops()
+    g = torch.Generator().manual_seed(M * 7 + N * 3 + K + ta * 2 + tb + 1)
+    a = torch.randn((K, M) if ta else (M, K), generator=g)
+    b = torch.randn((N, K) if tb else (K, N), generator=g)
+    ar, br = a.bfloat16().double(), b.bfloat16().double()
+    ref = (ar.T if ta else ar) @ (br.T if tb else br)
+    with ops.compute_dtype("bf16"):
+        out = ops.gemm(a.to(DEV), b.to(DEV), ta, tb)
+    assert relerr(out, ref) < 2e-6 * math.sqrt(K)
+    # and it is what it says: within bf16 quantisation of the true fp32 product
+    true = (a.double().T if ta else a.double()) @ (b.double().T if tb else b.double())
+    assert relerr(out, true) < 2e-2
+
+
+def test_gemm_bf16_epilogue_and_wgrad():
+    ops = _ops()
+    from imagecaption_amd._capi import ACT_GELU
+    g = torch.Generator().manual_seed(13)
+    M, N, K = 200, 136, 96
+    x, w, b, r = torch.randn(M, K, generator=g), torch.randn(N, K, generator=g) / 8, torch.randn(N, generator=g), \
+        torch.randn(M, N, generator=g)
+    xr, wr = x.bfloat16().double(), w.bfloat16().double()
+    pre = torch.empty(M, N, device=DEV)
+    with ops.compute_dtype("bf16"):
+        out = ops.linear_fwd(x.to(DEV), w.to(DEV), b.to(DEV), act=ACT_GELU, pre=pre, addend=r.to(DEV))
+        dy = torch.randn(4096, N, generator=g)
+        xx = torch.randn(4096, K, generator=g)
+        dw = torch.empty(N, K, device=DEV)
+        db = torch.empty(N, device=DEV)
+        ops.linear_wgrad(dy.to(DEV), xx.to(DEV), dw=dw, db=db)
+    u = xr @ wr.T + b.double()
+    assert relerr(pre, u) < 1e-5 and relerr(out, gelu(u) + r.double()) < 1e-5
+    assert relerr(dw, dy.bfloat16().double().T @ xx.bfloat16().double()) < 2e-5
+    assert relerr(db, dy.bfloat16().double().sum(0)) < 2e-5

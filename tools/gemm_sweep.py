@@ -21,6 +21,10 @@ def timeit(fn, n=10):
     return e0.elapsed_time(e1) / n * 1e-3
 
 l = _capi.lib()
+DT = os.environ.get("SWEEP_DTYPE", "fp32")
+ops.COMPUTE_DTYPE = {"fp32": _capi.F32, "bf16": _capi.BF16}[DT]
+CANDS = [(128, 128), (128, 64), (64, 128), (64, 64)] if DT == "fp32" else [(128, 128), (64, 64)]
+BKS = [16, 32] if DT == "fp32" else [0]
 for ta, tb, M, N, K in SHAPES:
     a = torch.randn((K, M) if ta else (M, K), device="cuda")
     b = torch.randn((N, K) if tb else (K, N), device="cuda")
@@ -29,7 +33,7 @@ for ta, tb, M, N, K in SHAPES:
     l.capdec_gemm_tune(0, 0, 0, 0)
     t = timeit(lambda: ops.gemm(a, b, ta, tb, out=out))
     res.append(("auto", t))
-    for (bm, bn), sp, bk in itertools.product([(128, 128), (128, 64), (64, 128), (64, 64)], [1, 2, 4, 8, 16], [16, 32]):
+    for (bm, bn), sp, bk in itertools.product(CANDS, [1, 2, 4, 8, 16], BKS):
         if sp > 1 and K // sp < 128: continue
         if sp > 1 and M * N * sp * 4 > (1 << 30): continue
         l.capdec_gemm_tune(bm, bn, sp, bk)

@@ -92,8 +92,8 @@ def stream():
 _ws = {}
 
 
-def workspace(nbytes, device):
-    key = (device.type, device.index)
+def workspace(nbytes, device, tag="main"):
+    key = (device.type, device.index, tag)
     w = _ws.get(key)
     if w is None or w.numel() < nbytes:
         size = max(int(nbytes), 64 << 20)

@@ -273,14 +273,18 @@ GemmPlan plan_gemm_bf16(int M, int N, int K) {
         const int bm = g_gemm_force.bm == 128 && g_gemm_force.bn == 128 ? 128 : 64;
         return GemmPlan{bm, bm, HBK, cdiv(K, ks), ks};
     }
-    int bm = 128;
-    long tiles = (long)cdiv(M, 128) * cdiv(N, 128);
-    if (tiles < 512) {
-        bm = 64;
-        tiles = (long)cdiv(M, 64) * cdiv(N, 64);
+    // calibrated on profiles/r01_gemm_sweep_bf16.txt: short-K products want many small workgroups
+    // (latency hiding by occupancy); long-K products (weight gradients, the vocab input gradient)
+    // want 128x128 tiles and enough K slices for >= 1024 workgroups.
+    int bm = 64, split = 1;
+    if (K >= 4096) {
+        bm = 128;
+        const long tiles = (long)cdiv(M, 128) * cdiv(N, 128);
+        while (tiles * split < 1024 && K / (split * 2) >= 512 && split < 32) split *= 2;
+    } else {
+        const long tiles = (long)cdiv(M, 64) * cdiv(N, 64);
+        while (tiles * split < 256 && K / (split * 2) >= 256 && split < 16) split *= 2;
     }
-    int split = 1;
-    while (tiles * split < 512 && split < 16 && K / (split * 2) >= 256) split *= 2;
     const int ks = cdiv(cdiv(K, split), HBK) * HBK;
     return GemmPlan{bm, bm, HBK, cdiv(K, ks), ks};
 }

@@ -37,6 +37,34 @@ class compute_dtype:
         COMPUTE_DTYPE = self.prev
 
 
+# Weight-gradient products may run on a side stream (trainer only): they depend on nothing later in
+# backward, so they fill the matrix pipes while the critical path runs its latency-bound kernels
+# (LayerNorm / attention backward, small input-gradient GEMMs with ragged tile counts).
+class SideStream:
+    def __init__(self, device):
+        self.stream = torch.cuda.Stream(device=device)
+        self.keep = []       # tensors the side stream still reads; released at join()
+        self.pending = False
+
+    def run(self, fn, *tensors):
+        ev = torch.cuda.Event()
+        ev.record()
+        self.stream.wait_event(ev)
+        with torch.cuda.stream(self.stream):
+            fn()
+        self.keep.extend(tensors)
+        self.pending = True
+
+    def join(self):
+        if self.pending:
+            torch.cuda.current_stream().wait_stream(self.stream)
+            self.keep.clear()
+            self.pending = False
+
+
+SIDE = None  # set by CaptionTrainer around backward
+
+
 # Optional per-launch timing (bench.py): when PROFILE is a list, GEMM / attention launches are
 # bracketed by events on torch's current stream -- the stream the kernels are launched on.
 PROFILE = None
@@ -74,7 +102,7 @@ def _mat(t, name):
 
 
 def gemm(a, b, trans_a, trans_b, out=None, bias=None, addend=None, pre=None, aux=None, colsum=None, act=ACT_NONE,
-         drop_p=0.0, seed=0):
+         drop_p=0.0, seed=0, ws_tag="main"):
     """out[M,N] = epilogue(op(a) @ op(b)); see capdec_gemm in include/capdec.h."""
     _mat(a, "gemm.a"), _mat(b, "gemm.b")
     M, K = (a.shape[1], a.shape[0]) if trans_a else (a.shape[0], a.shape[1])
@@ -101,7 +129,7 @@ def gemm(a, b, trans_a, trans_b, out=None, bias=None, addend=None, pre=None, aux
     ep.act, ep.drop_p, ep.drop_seed = act, float(drop_p), int(seed) & 0xFFFFFFFFFFFFFFFF
     l = lib()
     need = l.capdec_gemm_workspace_bytes(M, N, K)
-    ws = _capi.workspace(need, a.device) if need else None
+    ws = _capi.workspace(need, a.device, ws_tag) if need else None
     with _Timed(f"gemm_{'t' if trans_a else 'n'}{'t' if trans_b else 'n'}_{M}x{N}x{K}", 2.0 * M * N * K):
         check(l.capdec_gemm(int(trans_a), int(trans_b), M, N, K, ptr(a), a.stride(0), ptr(b), b.stride(0), ptr(out),
                             out.stride(0), C.byref(ep), COMPUTE_DTYPE, ptr(ws), ws.numel() if ws is not None else 0, stream()),
@@ -121,7 +149,13 @@ def linear_dgrad(dy, w, out=None, addend=None, gelu_pre=None, drop_p=0.0, seed=0
 
 
 def linear_wgrad(dy, x, dw=None, db=None):
-    """dw[N,K] = dy.T @ x, db[N] = column sums of dy (fused into the same kernel)."""
+    """dw[N,K] = dy.T @ x, db[N] = column sums of dy (fused into the same kernel).
+
+    With a SideStream active and caller-owned outputs, the product is enqueued on the side stream
+    (ordered after everything enqueued so far on the current stream) and the call returns at once."""
+    if SIDE is not None and dw is not None:
+        SIDE.run(lambda: gemm(dy, x, True, False, out=dw, colsum=db, ws_tag="side"), dy, x)
+        return dw
     return gemm(dy, x, True, False, out=dw, colsum=db)
 
 

@@ -26,7 +26,8 @@ from .parallel import BucketReducer, FlatParams, decoder_param_groups
 
 class CaptionTrainer:
     def __init__(self, model, lr=1e-3, betas=(0.9, 0.999), eps=1e-8, weight_decay=0.01, max_norm=1.0,
-                 smooth_factor=0.1, dropout=0.1, seed=0, process_group=None, overlap=True, dtype="fp32"):
+                 smooth_factor=0.1, dropout=0.1, seed=0, process_group=None, overlap=True, dtype="fp32",
+                 side_stream_wgrad=True):
         self.model = model
         self.lr, self.betas, self.eps, self.wd = lr, betas, eps, weight_decay
         self.max_norm, self.smooth, self.p, self.seed = max_norm, smooth_factor, dropout, seed
@@ -50,6 +51,7 @@ class CaptionTrainer:
         dev = self.flat_p.device
         self.gnorm_sq = torch.zeros(1, dtype=torch.float32, device=dev)
         self.reducer = BucketReducer(self.flat_g, self.bucket_ranges, process_group, overlap)
+        self.side = ops.SideStream(dev) if (side_stream_wgrad and dev.type == "cuda") else None
         self._refresh_views()
 
     def _refresh_views(self):
@@ -66,8 +68,14 @@ class CaptionTrainer:
 
     # ---- one iteration of ref train.py:24-61 ---------------------------------------------------------
     def forward_backward(self, features, captions, train=True, keep_logits=False):
-        with ops.compute_dtype(self.dtype):
-            return self._forward_backward(features, captions, train, keep_logits)
+        prev, ops.SIDE = ops.SIDE, self.side
+        try:
+            with ops.compute_dtype(self.dtype):
+                return self._forward_backward(features, captions, train, keep_logits)
+        finally:
+            if self.side is not None:
+                self.side.join()
+            ops.SIDE = prev
 
     def _forward_backward(self, features, captions, train, keep_logits):
         m = self.model
@@ -92,6 +100,8 @@ class CaptionTrainer:
         dy = engine.head_bwd(self.P_head, self.G_head, sv_head, dlogits, dp)
 
         def after_layer(l):
+            if self.side is not None and self.reducer.world > 1:
+                self.side.join()  # this layer's weight gradients must be complete before its bucket is reduced
             if l == self.nl - 1:
                 self.reducer.reduce(nb - 1)  # head + final norm are complete once layer L-1 started
             self.reducer.reduce(1 + l)
@@ -101,6 +111,8 @@ class CaptionTrainer:
         engine.proj_bwd(self.P_proj, self.G_proj, sv_proj, dmem, dp)
         ops.embed_bwd(tgt_in, dx.view(B, T, -1), m.embedding.weight.shape[0], dp.p, dp.seed(engine.S_EMBED),
                       dE=m.embedding.weight.grad)
+        if self.side is not None:
+            self.side.join()
         self.reducer.reduce(0)
         self.reducer.finish()
         return loss, keep

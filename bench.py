@@ -122,8 +122,12 @@ def profile_step(trainer, feats, ids):
     """One instrumented step: HIP-event duration of every GEMM / attention launch (on the launch stream)."""
     from imagecaption_amd import ops
     ops.PROFILE = []
-    trainer.step(feats, ids)
-    torch.cuda.synchronize()
+    side, trainer.side = trainer.side, None  # serialise on one stream: per-launch durations without overlap
+    try:
+        trainer.step(feats, ids)
+        torch.cuda.synchronize()
+    finally:
+        trainer.side = side
     rec, ops.PROFILE = ops.PROFILE, None
     agg = {}
     for kind, work, nbytes, e0, e1 in rec:
@@ -152,7 +156,7 @@ def main():
     ap.add_argument("--batch", type=int, default=0, help="per-GPU batch (default: the config's)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-dropout", action="store_true", help="eval-mode step (parity runs only; not the metric)")
-    ap.add_argument("--dtype", default="fp32", choices=["fp32", "bf16"],
+    ap.add_argument("--dtype", default="fp32", choices=["fp32", "f32x3", "bf16"],
                     help="fp32 = reference precision (the headline); bf16 = bf16 MFMA products, fp32 elsewhere")
     ap.add_argument("--no-decode", action="store_true")
     ap.add_argument("--decode-images", type=int, default=1024, help="images per GPU for the decode leg")

@@ -9,9 +9,9 @@ import os
 import torch
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libcapdec.so")
+LIB_PATH = os.environ.get("CAPDEC_LIBRARY") or os.path.join(_HERE, "libcapdec.so")  # override: kernel experiments
 
-F32, BF16 = 0, 1
+F32, BF16, F32X3 = 0, 1, 2
 ACT_NONE, ACT_GELU, ACT_GELU_BWD = 0, 1, 2
 
 _vp, _i, _f, _u64, _sz = C.c_void_p, C.c_int, C.c_float, C.c_uint64, C.c_size_t

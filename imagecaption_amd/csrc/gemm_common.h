@@ -45,5 +45,7 @@ static inline int cdiv(int a, int b) { return (a + b - 1) / b; }
 
 GemmPlan plan_gemm_bf16(int M, int N, int K);
 void launch_gemm_bf16(const GemmParams& p, const GemmPlan& pl, bool AK, bool BKM, bool vec, hipStream_t st);
+GemmPlan plan_gemm_f32x3(int M, int N, int K);
+int launch_gemm_f32x3(const GemmParams& p, const GemmPlan& pl, bool AK, bool BKM, bool vec, hipStream_t st);
 
 }  // namespace capdec

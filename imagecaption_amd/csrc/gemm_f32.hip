@@ -361,8 +361,9 @@ extern "C" int capdec_gemm_tune(int bm, int bn, int split, int bk) {
 
 extern "C" size_t capdec_gemm_workspace_bytes(int M, int N, int K) {
     if (M <= 0 || N <= 0 || K <= 0) return 0;
-    const GemmPlan a = plan_gemm(M, N, K), b = plan_gemm_bf16(M, N, K);
-    const int split = a.split > b.split ? a.split : b.split;
+    const GemmPlan a = plan_gemm(M, N, K), b = plan_gemm_bf16(M, N, K), c = plan_gemm_f32x3(M, N, K);
+    int split = a.split > b.split ? a.split : b.split;
+    if (c.split > split) split = c.split;
     if (split <= 1) return 0;
     return ((size_t)split * M * N + (size_t)split * M) * sizeof(float);
 }
@@ -370,7 +371,8 @@ extern "C" size_t capdec_gemm_workspace_bytes(int M, int N, int K) {
 extern "C" int capdec_gemm(int transA, int transB, int M, int N, int K, const void* A, int lda, const void* B,
                            int ldb, void* C, int ldc, const capdec_epilogue* ep, int dtype, void* workspace,
                            size_t workspace_bytes, capdec_stream_t stream) {
-    CAPDEC_REQUIRE(dtype == CAPDEC_F32 || dtype == CAPDEC_BF16, "capdec_gemm: dtype %d not supported", dtype);
+    CAPDEC_REQUIRE(dtype == CAPDEC_F32 || dtype == CAPDEC_BF16 || dtype == CAPDEC_F32X3,
+                   "capdec_gemm: dtype %d not supported", dtype);
     CAPDEC_REQUIRE(M > 0 && N > 0 && K > 0, "capdec_gemm: bad shape M=%d N=%d K=%d", M, N, K);
     CAPDEC_REQUIRE(A && B && C, "capdec_gemm: null operand");
     CAPDEC_REQUIRE(lda >= (transA ? M : K) && ldb >= (transB ? K : N) && ldc >= N,
@@ -397,7 +399,8 @@ extern "C" int capdec_gemm(int transA, int transB, int M, int N, int K, const vo
         CAPDEC_REQUIRE(!ep->addend || ep->ld_addend >= N, "capdec_gemm: ld_addend too small");
         CAPDEC_REQUIRE(ep->drop_p >= 0.f && ep->drop_p < 1.f, "capdec_gemm: drop_p out of range");
     }
-    GemmPlan pl = dtype == CAPDEC_BF16 ? plan_gemm_bf16(M, N, K) : plan_gemm(M, N, K);
+    GemmPlan pl = dtype == CAPDEC_BF16 ? plan_gemm_bf16(M, N, K)
+                  : dtype == CAPDEC_F32X3 ? plan_gemm_f32x3(M, N, K) : plan_gemm(M, N, K);
     if (pl.split > 1) {
         const size_t need = ((size_t)pl.split * M * N + (size_t)pl.split * M) * sizeof(float);
         if (!workspace || workspace_bytes < need) {
@@ -415,6 +418,9 @@ extern "C" int capdec_gemm(int transA, int transB, int M, int N, int K, const vo
     hipStream_t st = (hipStream_t)stream;
     if (dtype == CAPDEC_BF16) {
         launch_gemm_bf16(p, pl, AK, BKM, vec, st);
+    } else if (dtype == CAPDEC_F32X3) {
+        const int lrc = launch_gemm_f32x3(p, pl, AK, BKM, vec, st);
+        if (lrc) return lrc;
     } else if (pl.bk == 32) {
         if (pl.bm == 128 && pl.bn == 128) launch_cfg<128, 128, 32>(p, AK, BKM, vec, grid, st);
         else if (pl.bm == 128 && pl.bn == 64) launch_cfg<128, 64, 32>(p, AK, BKM, vec, grid, st);

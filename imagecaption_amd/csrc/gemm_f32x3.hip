@@ -1,0 +1,374 @@
+// Split-fp32 GEMM (dtype = CAPDEC_F32X3): fp32 accuracy on the bf16 matrix cores.
+//
+// Every fp32 operand element a is split exactly into three bf16 terms, a = a0 + a1 + a2
+// (a0 = rne_bf16(a), a1 = rne_bf16(a - a0), a2 = a - a0 - a1: 3 x 8 significand bits + signs cover
+// fp32's 24 bits, so the split loses nothing), and the product is assembled from the six partial
+// products of weight >= 2^-16,
+//     a*b ~= a0 b0 + (a0 b1 + a1 b0) + (a0 b2 + a1 b1 + a2 b0),
+// each a v_mfma_f32_32x32x16_bf16 with fp32 accumulation (bf16 x bf16 is exact in fp32).  The dropped
+// terms a1 b2 + a2 b1 + a2 b2 are <= 2^-23 |ab| worst case, ~2^-26 typical: below the rounding a fp32
+// FMA chain commits per step, so the result is as accurate as the exact-fp32 MFMA path of
+// gemm_f32.hip (tests/test_ops_gpu.py compares both against float64) at 16/6 = 2.7x its matrix rate.
+// Non-finite operands come out as NaN (inf - inf in the residual), finite data is unaffected.
+//
+// Block tile BM x BN x 32, 512 threads: four consumer waves (2 x 2 over the tile, one per SIMD) run the
+// MFMA chain, four producer waves (their SIMD partners) load, split and store the next k-tile;
+// double-buffered LDS (dynamic, up to 120 KiB), one s_barrier per k-tile.
+// LDS images, three bf16 planes per operand:
+//   k-contiguous operand  : [row][40]   (80-B rows)  -> fragment = one ds_read_b128, conflict-free
+//   row-contiguous operand: [k][rows+32] (rows*2+64 B per k) -> written as loaded (no register
+//                           transpose), fragment = two ds_read_b64_tr_b16 (hardware transpose),
+//                           4 k-rows land on 4 distinct 64-B bank quarters
+#include "common.h"
+#include "gemm_common.h"
+
+namespace capdec {
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
+typedef short s16x4 __attribute__((ext_vector_type(4)));
+
+constexpr int XBK = 32;   // k-tile
+constexpr int XLDK = 40;  // row stride of the [row][k] image, bf16 elements
+constexpr int XPAD = 32;  // row padding of the [k][row] image, bf16 elements
+
+struct Split4 {
+    bf16x4 t0, t1, t2;
+};
+
+__device__ __forceinline__ Split4 split4(float4 v) {
+    const f32x4 x = {v.x, v.y, v.z, v.w};
+    Split4 s;
+    s.t0 = __builtin_convertvector(x, bf16x4);
+    const f32x4 r1 = x - __builtin_convertvector(s.t0, f32x4);
+    s.t1 = __builtin_convertvector(r1, bf16x4);
+    const f32x4 r2 = r1 - __builtin_convertvector(s.t1, f32x4);
+    s.t2 = __builtin_convertvector(r2, bf16x4);
+    return s;
+}
+
+template <bool VEC>
+__device__ __forceinline__ float4 xload4(const float* ptr, bool ok, int rem) {
+    float4 r = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (!ok || rem <= 0) return r;
+    if (VEC && rem >= 4) return *reinterpret_cast<const float4*>(ptr);
+    r.x = ptr[0];
+    if (rem > 1) r.y = ptr[1];
+    if (rem > 2) r.z = ptr[2];
+    if (rem > 3) r.w = ptr[3];
+    return r;
+}
+
+__device__ __forceinline__ bf16x4 lds_read_tr(const __bf16* ptr) {
+    typedef __attribute__((address_space(3))) s16x4 lds_s16x4;
+    const s16x4 v = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4*)ptr);
+    return __builtin_bit_cast(bf16x4, v);
+}
+
+// one operand: global -> registers -> three-plane LDS image (producer waves); fragment reads (consumers)
+template <int ROWS, bool KC, bool VEC>
+struct Operand {
+    static constexpr int NT = 256;                                    // producer threads
+    static constexpr int REGS = ROWS * XBK / 4 / NT;                  // float4 per producer thread per k-tile
+    static constexpr int LD = KC ? XLDK : ROWS + XPAD;                // image row stride (bf16 elements)
+    static constexpr int PLANE = KC ? ROWS * XLDK : XBK * (ROWS + XPAD);
+    static constexpr int RQ = ROWS / 4;
+
+    // src(row, k) = base[row * ld + k] if KC else base[k * ld + row]
+    template <bool INTERIOR>
+    __device__ static __forceinline__ void gload(float4* r, const float* base, int ld, int row0, int nrows, int k0, int kend,
+                                                 int tid) {
+#pragma unroll
+        for (int i = 0; i < REGS; ++i) {
+            const int f = tid + i * NT;
+            if (KC) {
+                const int row = f >> 3, kq = f & 7;
+                const int gr = row0 + row, gk = k0 + kq * 4;
+                const float* ptr = base + (size_t)gr * ld + gk;
+                r[i] = INTERIOR ? *reinterpret_cast<const float4*>(ptr) : xload4<VEC>(ptr, gr < nrows, kend - gk);
+            } else {
+                const int kr = f / RQ, rq = f % RQ;
+                const int gk = k0 + kr, gr = row0 + rq * 4;
+                const float* ptr = base + (size_t)gk * ld + gr;
+                r[i] = INTERIOR ? *reinterpret_cast<const float4*>(ptr) : xload4<VEC>(ptr, gk < kend, nrows - gr);
+            }
+        }
+    }
+
+    __device__ static __forceinline__ void lstore(const float4* r, __bf16* img, int tid) {
+#pragma unroll
+        for (int i = 0; i < REGS; ++i) {
+            const int f = tid + i * NT;
+            const int off = KC ? (f >> 3) * XLDK + (f & 7) * 4 : (f / RQ) * LD + (f % RQ) * 4;
+            const Split4 s = split4(r[i]);
+            *reinterpret_cast<bf16x4*>(img + off) = s.t0;
+            *reinterpret_cast<bf16x4*>(img + PLANE + off) = s.t1;
+            *reinterpret_cast<bf16x4*>(img + 2 * PLANE + off) = s.t2;
+        }
+    }
+
+    // fragment of 32 rows starting at `row` for MFMA k-step ks (16 k), plane `pl`
+    __device__ static __forceinline__ bf16x8 frag(const __bf16* img, int pl, int row, int ks, int lane) {
+        const __bf16* base = img + pl * PLANE;
+        if (KC) {
+            return *reinterpret_cast<const bf16x8*>(base + (row + (lane & 31)) * XLDK + ks * 16 + (lane >> 5) * 8);
+        } else {
+            const int q = (lane & 15) >> 2, pp = lane & 3;
+            const __bf16* ptr = base + (ks * 16 + (lane >> 5) * 8 + q) * LD + row + ((lane >> 4) & 1) * 16 + pp * 4;
+            const bf16x4 lo = lds_read_tr(ptr);
+            const bf16x4 hi = lds_read_tr(ptr + 4 * LD);
+            return __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7);
+        }
+    }
+};
+
+// Producer waves (4..7): stream k-tiles HBM -> registers -> split -> LDS.  The LDS image runs one
+// tile ahead of the consumers; two more tiles are in flight in two register stages.  The steady-state
+// loop is branch-free (tile indices past the end are clamped: loaded again, stored to a buffer nobody
+// reads any more) so that the compiler can count outstanding loads and wait for the older stage only.
+// One s_barrier per k-tile, matched by the consumers.
+template <int BM, int BN, bool AK, bool BKM, bool VEC, bool INTERIOR, bool COLSUM>
+__device__ __forceinline__ void x3_produce(const GemmParams& p, __bf16* smem, int m0, int n0, int kbeg, int kend, int nk,
+                                           int ptid) {
+    typedef Operand<BM, AK, VEC> OA;
+    typedef Operand<BN, BKM, VEC> OB;
+    constexpr int BUF = 3 * (OA::PLANE + OB::PLANE);
+    float4 ra0[OA::REGS], rb0[OB::REGS], ra1[OA::REGS], rb1[OB::REGS];
+    float csum = 0.f;
+    auto fetch = [&](float4* ra, float4* rb, int kt) {
+        const int k0 = kbeg + min(kt, nk - 1) * XBK;
+        OA::template gload<INTERIOR>(ra, p.A, p.lda, m0, p.M, k0, kend, ptid);
+        OB::template gload<INTERIOR>(rb, p.B, p.ldb, n0, p.N, k0, kend, ptid);
+    };
+    auto stash = [&](const float4* ra, const float4* rb, int kt) {  // tile kt -> LDS buffer kt & 1
+        __bf16* An = smem + (kt & 1) * BUF;
+        OA::lstore(ra, An, ptid);
+        OB::lstore(rb, An + 3 * OA::PLANE, ptid);
+    };
+    auto colsum_of = [&](int kt) {  // A image is [k][m]; the three planes sum to the fp32 value exactly
+        if (COLSUM && ptid < BM) {
+            const __bf16* As = smem + (kt & 1) * BUF;
+#pragma unroll 8
+            for (int k = 0; k < XBK; ++k)
+                csum += ((float)As[k * OA::LD + ptid] + (float)As[OA::PLANE + k * OA::LD + ptid]) +
+                        (float)As[2 * OA::PLANE + k * OA::LD + ptid];
+        }
+    };
+    if (nk <= 0) {
+        __syncthreads();
+        return;
+    }
+    fetch(ra0, rb0, 0);
+    fetch(ra1, rb1, 1);
+    stash(ra0, rb0, 0);
+    fetch(ra0, rb0, 2);
+    __syncthreads();
+    // entering iteration kt (even): tile kt+1 is in stage 1, tile kt+2 in stage 0
+    int kt = 0;
+    for (; kt + 1 < nk; kt += 2) {
+        stash(ra1, rb1, kt + 1);
+        fetch(ra1, rb1, kt + 3);
+        colsum_of(kt);
+        __syncthreads();
+        stash(ra0, rb0, kt + 2);
+        fetch(ra0, rb0, kt + 4);
+        colsum_of(kt + 1);
+        __syncthreads();
+    }
+    if (kt < nk) {  // odd tile count: the last tile is already in LDS
+        colsum_of(kt);
+        __syncthreads();
+    }
+    if (COLSUM && ptid < BM && m0 + ptid < p.M) {
+        if (gridDim.z > 1) p.ws_colsum[(size_t)blockIdx.z * p.M + m0 + ptid] = csum;
+        else p.colsum[m0 + ptid] = csum;
+    }
+}
+
+// 512 threads: waves 0..3 multiply (2 x 2 over the block tile, one per SIMD), waves 4..7 feed them.
+// A SIMD's consumer and producer wave issue side by side: the matrix pipe runs the consumer's MFMA
+// chain while the producer's loads, splits and LDS stores use the vector / memory issue slots.
+template <int BM, int BN, bool AK, bool BKM, bool VEC>
+__global__ __launch_bounds__(512) void gemm_f32x3_kernel(GemmParams p) {
+    typedef Operand<BM, AK, VEC> OA;
+    typedef Operand<BN, BKM, VEC> OB;
+    constexpr int TM = BM / 64, TN = BN / 64;
+    constexpr int BUF = 3 * (OA::PLANE + OB::PLANE);
+    extern __shared__ __attribute__((aligned(16))) __bf16 x3_smem[];
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63, wave = tid >> 6;
+    const int nwg = gridDim.x;
+    int wg = blockIdx.x;
+    {
+        const int q = nwg >> 3, r = nwg & 7, xcd = wg & 7;
+        wg = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (wg >> 3);
+    }
+    int tile_m, tile_n;
+    {
+        const int tiles_m = nwg / p.tiles_n;
+        const int per_group = 8 * p.tiles_n;
+        const int gid = wg / per_group, first_m = gid * 8;
+        const int gsz = min(tiles_m - first_m, 8);
+        const int in_g = wg - gid * per_group;
+        tile_m = first_m + in_g % gsz;
+        tile_n = in_g / gsz;
+    }
+    const int m0 = tile_m * BM, n0 = tile_n * BN;
+    const int kbeg = blockIdx.z * p.ksplit;
+    const int kend = min(p.K, kbeg + p.ksplit);
+    const int nk = (kend - kbeg + XBK - 1) / XBK;
+
+    if (wave >= 4) {
+        const bool interior = VEC && (m0 + BM <= p.M) && (n0 + BN <= p.N) && ((kend - kbeg) % XBK == 0);
+        const bool do_colsum = (!AK) && p.colsum != nullptr && tile_n == 0;
+        const int ptid = tid - 256;
+        if (do_colsum) {
+            if (interior) x3_produce<BM, BN, AK, BKM, VEC, true, !AK>(p, x3_smem, m0, n0, kbeg, kend, nk, ptid);
+            else x3_produce<BM, BN, AK, BKM, VEC, false, !AK>(p, x3_smem, m0, n0, kbeg, kend, nk, ptid);
+        } else {
+            if (interior) x3_produce<BM, BN, AK, BKM, VEC, true, false>(p, x3_smem, m0, n0, kbeg, kend, nk, ptid);
+            else x3_produce<BM, BN, AK, BKM, VEC, false, false>(p, x3_smem, m0, n0, kbeg, kend, nk, ptid);
+        }
+        return;
+    }
+
+    const int l31 = lane & 31, half = lane >> 5;
+    const int wrow = (wave >> 1) * (BM / 2), wcol = (wave & 1) * (BN / 2);
+    f32x16 acc[TM][TN], cor[TM][TN];
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int j = 0; j < TN; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f, cor[i][j][r] = 0.f;
+
+    __syncthreads();
+    for (int kt = 0; kt < nk; ++kt) {
+        const __bf16* As = x3_smem + (kt & 1) * BUF;
+        const __bf16* Bs = As + 3 * OA::PLANE;
+#pragma unroll
+        for (int ks = 0; ks < XBK / 16; ++ks) {
+            bf16x8 af[3][TM], bf[3][TN];
+#pragma unroll
+            for (int pl = 0; pl < 3; ++pl) {
+#pragma unroll
+                for (int i = 0; i < TM; ++i) af[pl][i] = OA::frag(As, pl, wrow + i * 32, ks, lane);
+#pragma unroll
+                for (int j = 0; j < TN; ++j) bf[pl][j] = OB::frag(Bs, pl, wcol + j * 32, ks, lane);
+            }
+            // The five correction products (<= 2^-8 of the main term) have their own accumulator: their
+            // roundings are relative to a 256x smaller sum, and the main accumulator rounds once per
+            // 16 k instead of once per partial product.
+#pragma unroll
+            for (int i = 0; i < TM; ++i)
+#pragma unroll
+                for (int j = 0; j < TN; ++j) {
+                    f32x16 c = cor[i][j];
+                    c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[2][i], bf[0][j], c, 0, 0, 0);
+                    c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[0][i], bf[2][j], c, 0, 0, 0);
+                    c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[1][i], bf[1][j], c, 0, 0, 0);
+                    c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[1][i], bf[0][j], c, 0, 0, 0);
+                    c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[0][i], bf[1][j], c, 0, 0, 0);
+                    cor[i][j] = c;
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[0][i], bf[0][j], acc[i][j], 0, 0, 0);
+                }
+        }
+        __syncthreads();
+    }
+
+    const bool split = gridDim.z > 1;
+    float* wsz = split ? p.ws + (size_t)blockIdx.z * p.M * p.N : nullptr;
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int j = 0; j < TN; ++j) {
+            const int n = n0 + wcol + j * 32 + l31;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int m = m0 + wrow + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * half;
+                if (m < p.M && n < p.N) {
+                    const float v = acc[i][j][r] + cor[i][j][r];
+                    if (split) wsz[(size_t)m * p.N + n] = v;
+                    else p.C[(size_t)m * p.ldc + n] = epilogue_apply(p, v, m, n);
+                }
+            }
+        }
+}
+
+template <int BM, int BN, bool AK, bool BKM, bool VEC>
+static int launch_one(const GemmParams& p, dim3 grid, hipStream_t st) {
+    constexpr size_t lds = 2 * 3 * (size_t)(Operand<BM, AK, VEC>::PLANE + Operand<BN, BKM, VEC>::PLANE) * sizeof(__bf16);
+    static bool configured[64] = {};
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) return CAPDEC_ERR_LAUNCH;
+    if (!configured[dev]) {
+        if (hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_f32x3_kernel<BM, BN, AK, BKM, VEC>),
+                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess) {
+            set_error("capdec_gemm(f32x3): cannot reserve %zu bytes of LDS", lds);
+            return CAPDEC_ERR_LAUNCH;
+        }
+        configured[dev] = true;
+    }
+    hipLaunchKernelGGL((gemm_f32x3_kernel<BM, BN, AK, BKM, VEC>), grid, dim3(512), lds, st, p);
+    return CAPDEC_OK;
+}
+
+template <int BM, int BN>
+static int launch_x3(const GemmParams& p, bool AK, bool BKM, bool vec, dim3 grid, hipStream_t st) {
+#define CAPDEC_LAUNCH(ak, bk, v) return launch_one<BM, BN, ak, bk, v>(p, grid, st)
+    if (vec) {
+        if (AK && BKM) CAPDEC_LAUNCH(true, true, true);
+        else if (AK && !BKM) CAPDEC_LAUNCH(true, false, true);
+        else if (!AK && !BKM) CAPDEC_LAUNCH(false, false, true);
+        else CAPDEC_LAUNCH(false, true, true);
+    } else {
+        if (AK && BKM) CAPDEC_LAUNCH(true, true, false);
+        else if (AK && !BKM) CAPDEC_LAUNCH(true, false, false);
+        else if (!AK && !BKM) CAPDEC_LAUNCH(false, false, false);
+        else CAPDEC_LAUNCH(false, true, false);
+    }
+#undef CAPDEC_LAUNCH
+}
+
+GemmPlan plan_gemm_f32x3(int M, int N, int K) {
+    if (g_gemm_force.bm) {
+        const int split = g_gemm_force.split > 0 ? g_gemm_force.split : 1;
+        const int ks = cdiv(cdiv(K, split), XBK) * XBK;
+        int bm = g_gemm_force.bm, bn = g_gemm_force.bn;
+        if (bm == 64 && bn == 128) bm = 128, bn = 64;  // not instantiated; nearest
+        return GemmPlan{bm, bn, XBK, cdiv(K, ks), ks};
+    }
+    // calibrated on tools/gemm_sweep.py (SWEEP_DTYPE=f32x3, profiles/r01_gemm_sweep_f32x3.txt).  The product is
+    // bound by operand bytes per CU, so: short K (forward / input-gradient shapes) -> many 64x64 workgroups,
+    // two per CU, whose prologue / epilogue overlap; long K (weight gradients, the vocab input gradient)
+    // -> 128x128 tiles, K split until ~1000 workgroups are in flight or a slice gets shorter than 1024.
+    int bm = 64, bn = 64, split = 1;
+    if (K >= 4096) {
+        const long t128 = (long)cdiv(M, 128) * cdiv(N, 128);
+        if (t128 >= 32) {
+            bm = bn = 128;
+            while (t128 * split < 1024 && K / (split * 2) >= 1024 && split < 32) split *= 2;
+        } else {
+            const long t64 = (long)cdiv(M, 64) * cdiv(N, 64);
+            while (t64 * split < 1024 && K / (split * 2) >= 512 && split < 32) split *= 2;
+        }
+    } else {
+        const long t64 = (long)cdiv(M, 64) * cdiv(N, 64);
+        while (t64 * split < 512 && K / (split * 2) >= 256 && split < 16) split *= 2;
+        if (split == 1 && t64 < 1024 && K >= 2048) split = 2;
+    }
+    const int ks = cdiv(cdiv(K, split), XBK) * XBK;
+    return GemmPlan{bm, bn, XBK, cdiv(K, ks), ks};
+}
+
+int launch_gemm_f32x3(const GemmParams& p, const GemmPlan& pl, bool AK, bool BKM, bool vec, hipStream_t st) {
+    dim3 grid(cdiv(p.M, pl.bm) * p.tiles_n, 1, pl.split);
+    if (pl.bm == 128 && pl.bn == 128) return launch_x3<128, 128>(p, AK, BKM, vec, grid, st);
+    if (pl.bm == 128 && pl.bn == 64) return launch_x3<128, 64>(p, AK, BKM, vec, grid, st);
+    return launch_x3<64, 64>(p, AK, BKM, vec, grid, st);
+}
+
+}  // namespace capdec

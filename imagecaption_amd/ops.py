@@ -26,7 +26,7 @@ class compute_dtype:
     """with ops.compute_dtype("bf16"): ...  -- scoped override of COMPUTE_DTYPE."""
 
     def __init__(self, name):
-        self.value = {"f32": F32, "fp32": F32, "bf16": _capi.BF16}[str(name).lower()]
+        self.value = {"f32": F32, "fp32": F32, "bf16": _capi.BF16, "f32x3": _capi.F32X3, "fp32x3": _capi.F32X3}[str(name).lower()]
 
     def __enter__(self):
         global COMPUTE_DTYPE
@@ -41,27 +41,51 @@ class compute_dtype:
 # backward, so they fill the matrix pipes while the critical path runs its latency-bound kernels
 # (LayerNorm / attention backward, small input-gradient GEMMs with ragged tile counts).
 class SideStream:
-    def __init__(self, device):
-        self.stream = torch.cuda.Stream(device=device)
-        self.keep = []       # tensors the side stream still reads; released at join()
+    """Side lanes for work that is off the critical path of a training step.
+
+    lane 0: weight-gradient GEMMs; lane 1: the image-memory branch (per-layer cross-attention K/V
+    projections in forward, the d(memory) accumulation chain in backward).  Each lane is one HIP
+    stream with its own split-K workspace; outputs are always allocated by the caller on the main
+    stream, so the caching allocator never sees a cross-stream free."""
+
+    def __init__(self, device, lanes=2):
+        self.streams = [torch.cuda.Stream(device=device) for _ in range(lanes)]
+        self.keep = []       # tensors a lane still reads; released at join()
         self.pending = False
 
-    def run(self, fn, *tensors):
+    def run(self, fn, *tensors, lane=0):
+        """Enqueue fn() on the lane, ordered after everything enqueued so far on the current stream.
+        Returns an event recorded after it (main-stream consumers wait on it)."""
+        global _WS_TAG
         ev = torch.cuda.Event()
         ev.record()
-        self.stream.wait_event(ev)
-        with torch.cuda.stream(self.stream):
-            fn()
+        st = self.streams[lane]
+        st.wait_event(ev)
+        prev, _WS_TAG = _WS_TAG, f"side{lane}"
+        try:
+            with torch.cuda.stream(st):
+                fn()
+                done = torch.cuda.Event()
+                done.record()
+        finally:
+            _WS_TAG = prev
         self.keep.extend(tensors)
         self.pending = True
+        return done
+
+    def wait_lane(self, lane):
+        torch.cuda.current_stream().wait_stream(self.streams[lane])
 
     def join(self):
         if self.pending:
-            torch.cuda.current_stream().wait_stream(self.stream)
+            cur = torch.cuda.current_stream()
+            for st in self.streams:
+                cur.wait_stream(st)
             self.keep.clear()
             self.pending = False
 
 
+_WS_TAG = "main"
 SIDE = None  # set by CaptionTrainer around backward
 
 
@@ -102,7 +126,7 @@ def _mat(t, name):
 
 
 def gemm(a, b, trans_a, trans_b, out=None, bias=None, addend=None, pre=None, aux=None, colsum=None, act=ACT_NONE,
-         drop_p=0.0, seed=0, ws_tag="main"):
+         drop_p=0.0, seed=0):
     """out[M,N] = epilogue(op(a) @ op(b)); see capdec_gemm in include/capdec.h."""
     _mat(a, "gemm.a"), _mat(b, "gemm.b")
     M, K = (a.shape[1], a.shape[0]) if trans_a else (a.shape[0], a.shape[1])
@@ -129,7 +153,7 @@ def gemm(a, b, trans_a, trans_b, out=None, bias=None, addend=None, pre=None, aux
     ep.act, ep.drop_p, ep.drop_seed = act, float(drop_p), int(seed) & 0xFFFFFFFFFFFFFFFF
     l = lib()
     need = l.capdec_gemm_workspace_bytes(M, N, K)
-    ws = _capi.workspace(need, a.device, ws_tag) if need else None
+    ws = _capi.workspace(need, a.device, _WS_TAG) if need else None
     with _Timed(f"gemm_{'t' if trans_a else 'n'}{'t' if trans_b else 'n'}_{M}x{N}x{K}", 2.0 * M * N * K):
         check(l.capdec_gemm(int(trans_a), int(trans_b), M, N, K, ptr(a), a.stride(0), ptr(b), b.stride(0), ptr(out),
                             out.stride(0), C.byref(ep), COMPUTE_DTYPE, ptr(ws), ws.numel() if ws is not None else 0, stream()),
@@ -154,7 +178,7 @@ def linear_wgrad(dy, x, dw=None, db=None):
     With a SideStream active and caller-owned outputs, the product is enqueued on the side stream
     (ordered after everything enqueued so far on the current stream) and the call returns at once."""
     if SIDE is not None and dw is not None:
-        SIDE.run(lambda: gemm(dy, x, True, False, out=dw, colsum=db, ws_tag="side"), dy, x)
+        SIDE.run(lambda: gemm(dy, x, True, False, out=dw, colsum=db), dy, x)
         return dw
     return gemm(dy, x, True, False, out=dw, colsum=db)
 

@@ -108,6 +108,8 @@ class CaptionTrainer:
 
         dx, dmem = engine.stack_bwd(self.P_layers, self.G_layers, dec.norm.weight, dec.norm.bias, dec.norm.weight.grad,
                                     dec.norm.bias.grad, sv_stack, dy, mem, B, T, S, self.nhead, True, dp, after_layer)
+        if self.side is not None:
+            self.side.wait_lane(1)  # d(memory) is complete
         engine.proj_bwd(self.P_proj, self.G_proj, sv_proj, dmem, dp)
         ops.embed_bwd(tgt_in, dx.view(B, T, -1), m.embedding.weight.shape[0], dp.p, dp.seed(engine.S_EMBED),
                       dE=m.embedding.weight.grad)

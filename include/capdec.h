@@ -30,7 +30,12 @@ extern "C" {
 typedef void* capdec_stream_t; /* hipStream_t */
 
 enum { CAPDEC_OK = 0, CAPDEC_ERR_ARG = -1, CAPDEC_ERR_LAUNCH = -2, CAPDEC_ERR_UNSUPPORTED = -3, CAPDEC_ERR_WORKSPACE = -4 };
-enum { CAPDEC_F32 = 0, CAPDEC_BF16 = 1 };
+/* compute type of capdec_gemm (storage is fp32 in all three):
+ *   CAPDEC_F32   exact fp32 MFMA (v_mfma_f32_32x32x2_f32)
+ *   CAPDEC_BF16  operands rounded to bf16, fp32 accumulate (mixed precision)
+ *   CAPDEC_F32X3 fp32 operands split exactly into 3 bf16 terms, 6 bf16 MFMA partial products, fp32
+ *                accumulate: fp32-level accuracy at 2.7x the fp32 matrix rate (csrc/gemm_f32x3.hip) */
+enum { CAPDEC_F32 = 0, CAPDEC_BF16 = 1, CAPDEC_F32X3 = 2 };
 enum { CAPDEC_ACT_NONE = 0, CAPDEC_ACT_GELU = 1, CAPDEC_ACT_GELU_BWD = 2 };
 
 int capdec_abi_version(void);

@@ -358,3 +358,78 @@ def test_gemm_bf16_epilogue_and_wgrad():
     assert relerr(pre, u) < 1e-5 and relerr(out, gelu(u) + r.double()) < 1e-5
     assert relerr(dw, dy.bfloat16().double().T @ xx.bfloat16().double()) < 2e-5
     assert relerr(db, dy.bfloat16().double().sum(0)) < 2e-5
+
+
+# ---------------------------------------------------------------------------------------------
+# split-fp32 mode (3 bf16 terms per operand, 6 bf16 MFMA partial products): held to the SAME bar as the
+# exact-fp32 MFMA path, and its error against float64 is compared with that path's directly.
+@pytest.mark.parametrize("M,N,K", [(1, 1, 4), (3, 50, 24), (37, 108, 64), (129, 257, 100), (256, 512, 512),
+                                    (300, 1000, 130), (5120, 128, 64), (64, 64, 2048), (70, 70, 5120), (33, 27, 21),
+                                    (640, 384, 96)])
+@pytest.mark.parametrize("ta,tb", [(0, 1), (0, 0), (1, 0), (1, 1)])
+def test_gemm_f32x3(M, N, K, ta, tb):
+    ops = _ops()
+    g = torch.Generator().manual_seed(M * 7 + N * 3 + K + ta * 2 + tb + 2)
+    a = torch.randn((K, M) if ta else (M, K), generator=g)
+    b = torch.randn((N, K) if tb else (K, N), generator=g)
+    ref = (a.T if ta else a).double() @ (b.T if tb else b).double()
+    with ops.compute_dtype("f32x3"):
+        out = ops.gemm(a.to(DEV), b.to(DEV), ta, tb)
+    assert relerr(out, ref) < 2e-6 * math.sqrt(K)
+
+
+def test_gemm_f32x3_identity_is_exact():
+    """The 3-term split loses nothing: I @ B returns B bit for bit, for values using all 24 bits."""
+    ops = _ops()
+    n = 160
+    g = torch.Generator().manual_seed(5)
+    b = torch.randn(n, n, generator=g) * torch.exp(4 * torch.randn(n, n, generator=g))
+    with ops.compute_dtype("f32x3"):
+        assert torch.equal(ops.gemm(torch.eye(n, device=DEV), b.to(DEV), 0, 0).cpu(), b)
+        assert torch.equal(ops.gemm(b.to(DEV), torch.eye(n, device=DEV), 0, 1).cpu(), b)
+        assert torch.equal(ops.gemm(b.to(DEV), torch.eye(n, device=DEV), 1, 0).cpu(), b.T)
+        assert torch.equal(ops.gemm(b.to(DEV), torch.eye(n, device=DEV), 1, 1).cpu(), b.T)
+
+
+@pytest.mark.parametrize("M,N,K,ta,tb", [(512, 512, 512, 0, 1), (1024, 640, 2048, 0, 0), (512, 1024, 5120, 1, 0)])
+def test_gemm_f32x3_error_matches_exact_fp32(M, N, K, ta, tb):
+    """RMS and max error against float64: the split product is no worse than the exact-fp32 MFMA
+    path (measured 0.5-0.75x: the main accumulator rounds once per 16 k, not once per 2 k)."""
+    ops = _ops()
+    g = torch.Generator().manual_seed(K + M)
+    a = torch.randn((K, M) if ta else (M, K), generator=g) * torch.exp(torch.randn(1, K if not ta else 1, generator=g)) \
+        if not ta else torch.randn(K, M, generator=g)
+    b = torch.randn((N, K) if tb else (K, N), generator=g)
+    ref = (a.T if ta else a).double() @ (b.T if tb else b).double()
+    exact = ops.gemm(a.to(DEV), b.to(DEV), ta, tb).double().cpu()
+    with ops.compute_dtype("f32x3"):
+        split = ops.gemm(a.to(DEV), b.to(DEV), ta, tb).double().cpu()
+    e_exact, e_split = (exact - ref), (split - ref)
+    rms = lambda e: float(e.pow(2).mean().sqrt())
+    print(f"rms exact {rms(e_exact):.3e} split {rms(e_split):.3e}  max exact {float(e_exact.abs().max()):.3e} "
+          f"split {float(e_split.abs().max()):.3e}")
+    assert rms(e_split) <= 1.1 * rms(e_exact)
+    assert float(e_split.abs().max()) <= 1.5 * float(e_exact.abs().max())
+
+
+def test_gemm_f32x3_epilogue_and_wgrad():
+    ops = _ops()
+    from imagecaption_amd._capi import ACT_GELU
+    g = torch.Generator().manual_seed(14)
+    M, N, K = 200, 136, 96
+    x, w, b, r = torch.randn(M, K, generator=g), torch.randn(N, K, generator=g) / 8, torch.randn(N, generator=g), \
+        torch.randn(M, N, generator=g)
+    pre = torch.empty(M, N, device=DEV)
+    with ops.compute_dtype("f32x3"):
+        out = ops.linear_fwd(x.to(DEV), w.to(DEV), b.to(DEV), act=ACT_GELU, pre=pre, addend=r.to(DEV))
+        dy = torch.randn(4096, N, generator=g)
+        xx = torch.randn(4096, K, generator=g)
+        dw = torch.empty(N, K, device=DEV)
+        db = torch.empty(N, device=DEV)
+        ops.linear_wgrad(dy.to(DEV), xx.to(DEV), dw=dw, db=db)
+        dx = ops.linear_dgrad(dy.to(DEV), w.to(DEV))
+    u = x.double() @ w.double().T + b.double()
+    assert relerr(pre, u) < 1e-5 and relerr(out, gelu(u) + r.double()) < 1e-5
+    assert relerr(dw, dy.double().T @ xx.double()) < 2e-5
+    assert relerr(db, dy.double().sum(0)) < 2e-5
+    assert relerr(dx, dy.double() @ w.double()) < 1e-5

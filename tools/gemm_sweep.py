@@ -22,8 +22,9 @@ def timeit(fn, n=10):
 
 l = _capi.lib()
 DT = os.environ.get("SWEEP_DTYPE", "fp32")
-ops.COMPUTE_DTYPE = {"fp32": _capi.F32, "bf16": _capi.BF16}[DT]
-CANDS = [(128, 128), (128, 64), (64, 128), (64, 64)] if DT == "fp32" else [(128, 128), (64, 64)]
+ops.COMPUTE_DTYPE = {"fp32": _capi.F32, "bf16": _capi.BF16, "f32x3": _capi.F32X3}[DT]
+CANDS = {"fp32": [(128, 128), (128, 64), (64, 128), (64, 64)], "bf16": [(128, 128), (64, 64)],
+         "f32x3": [(128, 128), (128, 64), (64, 64)]}[DT]
 BKS = [16, 32] if DT == "fp32" else [0]
 for ta, tb, M, N, K in SHAPES:
     a = torch.randn((K, M) if ta else (M, K), device="cuda")

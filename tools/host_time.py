@@ -1,0 +1,27 @@
+"""Host enqueue time vs device time of one training step (is the step launch-bound?)."""
+import sys, time, torch
+sys.path.insert(0, ".")
+import bench
+from imagecaption_amd import ImageCaptioningModel
+from imagecaption_amd.trainer import CaptionTrainer
+
+cfg = bench.CONFIGS["c2"]
+dtype = sys.argv[1] if len(sys.argv) > 1 else "fp32"
+dev = torch.device("cuda:0")
+torch.manual_seed(0)
+model = ImageCaptioningModel(cfg["vocab"], cfg["d"], cfg["heads"], cfg["layers"], feature_dim=cfg["din"]).to(dev)
+tr = CaptionTrainer(model, dtype=dtype)
+f, c = bench.synth_batch(cfg, cfg["batch"], dev, 0)
+for _ in range(5):
+    tr.step(f, c)
+torch.cuda.synchronize()
+for side in (True, False):
+    if not side:
+        tr.side = None
+    t0 = time.perf_counter()
+    for _ in range(20):
+        tr.step(f, c)
+    t1 = time.perf_counter()
+    torch.cuda.synchronize()
+    t2 = time.perf_counter()
+    print(f"{dtype} side={side}: host enqueue {(t1-t0)/20*1e3:.2f} ms/step, total {(t2-t0)/20*1e3:.2f} ms/step", flush=True)

@@ -118,13 +118,17 @@ def vocab_traffic(config):
         return json.load(f)["traffic_bytes"]
 
 
-def profile_step(trainer, feats, ids):
-    """One instrumented step: HIP-event duration of every GEMM / attention launch (on the launch stream)."""
+def profile_step(trainer, feats, ids, reps=3):
+    """``reps`` instrumented steps: HIP-event duration of every GEMM / attention launch (on the launch
+    stream).  Returned counts / work / seconds are per step (means over the reps)."""
     from imagecaption_amd import ops
-    ops.PROFILE = []
     side, trainer.side = trainer.side, None  # serialise on one stream: per-launch durations without overlap
     try:
-        trainer.step(feats, ids)
+        trainer.step(feats, ids)  # the single-stream step allocates differently: one untimed pass first
+        torch.cuda.synchronize()
+        ops.PROFILE = []
+        for _ in range(reps):
+            trainer.step(feats, ids)
         torch.cuda.synchronize()
     finally:
         trainer.side = side
@@ -144,6 +148,10 @@ def profile_step(trainer, feats, ids):
         d[1] += work
         d[2] += nbytes
         d[3] += e0.elapsed_time(e1) * 1e-3
+    for table in (agg, detail):
+        for v in table.values():
+            v[0] //= reps
+            v[1], v[2], v[3] = v[1] / reps, v[2] / reps, v[3] / reps
     return agg, detail
 
 
@@ -159,6 +167,7 @@ def main():
     ap.add_argument("--dtype", default="fp32", choices=["fp32", "f32x3", "bf16"],
                     help="fp32 = reference precision (the headline); bf16 = bf16 MFMA products, fp32 elsewhere")
     ap.add_argument("--no-decode", action="store_true")
+    ap.add_argument("--no-side-streams", action="store_true", help="single-stream step (diagnostic)")
     ap.add_argument("--decode-images", type=int, default=1024, help="images per GPU for the decode leg")
     ap.add_argument("--detail", action="store_true", help="print the per-shape kernel table to stderr")
     args = ap.parse_args()
@@ -190,7 +199,8 @@ def main():
     torch.manual_seed(42)
     model = ImageCaptioningModel(cfg["vocab"], cfg["d"], cfg["heads"], cfg["layers"], feature_dim=cfg["din"]).to(dev)
     model.train()
-    trainer = CaptionTrainer(model, dropout=0.0 if args.no_dropout else 0.1, seed=42, dtype=args.dtype)
+    trainer = CaptionTrainer(model, dropout=0.0 if args.no_dropout else 0.1, seed=42, dtype=args.dtype,
+                             side_stream_wgrad=not args.no_side_streams)
     feats, ids = synth_batch(cfg, cfg["batch"], dev, rank)
 
     for _ in range(args.warmup):

@@ -51,6 +51,7 @@ class CaptionTrainer:
         dev = self.flat_p.device
         self.gnorm_sq = torch.zeros(1, dtype=torch.float32, device=dev)
         self.reducer = BucketReducer(self.flat_g, self.bucket_ranges, process_group, overlap)
+        self._logits = None
         self.side = ops.SideStream(dev) if (side_stream_wgrad and dev.type == "cuda") else None
         self._refresh_views()
 
@@ -91,7 +92,12 @@ class CaptionTrainer:
         dec = m.transformer_decoder
         y = engine.stack_fwd(self.P_layers, dec.norm.weight, dec.norm.bias, x.view(B * T, -1), mem, B, T, S, self.nhead,
                              True, dp, sv_stack)
-        logits = engine.head_fwd(self.P_head, y, dp, sv_head)
+        # the logits block (B*T x V fp32, the step's largest tensor) is owned by the trainer: one allocation
+        # for the run instead of a 100+ MB request to the caching allocator every step
+        if self._logits is None or tuple(self._logits.shape) != (B * T, self.P_head["3.weight"].shape[0]):
+            self._logits = torch.empty((B * T, self.P_head["3.weight"].shape[0]), dtype=torch.float32,
+                                       device=features.device)
+        logits = engine.head_fwd(self.P_head, y, dp, sv_head, logits_out=self._logits)
         keep = logits.clone() if keep_logits else None
         rows, dlogits = ops.softmax_ce(logits, tgt_out.view(-1), self.smooth, grad_scale=1.0 / (B * T * self.world),
                                        in_place=True)

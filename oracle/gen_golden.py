@@ -12,6 +12,8 @@ Outputs (all small, data only):
 * tiny_S{1,5}.npz             tiny config: inputs, activations, logits, loss, every gradient, clip
                               norm; S=1 also holds the parameters after one AdamW step
 * c1_shape.npz                C1 shape (d=512, V=108, T=299, B=2): logits, loss, grad norm
+* c2_shape.npz                bench workload (C2, B=256): 64 sampled logit rows, loss, global and
+                              per-parameter gradient norms (weights are rebuilt from seed 42)
 * decode_tiny.npz             greedy / beam-3 / beam-5 ids + scores + logit-gap margins (tiny config)
 """
 import json
@@ -132,6 +134,35 @@ def gen_c1_shape():
     print(f"c1 shape: loss {loss.item():.6f} grad-norm {gn.item():.6f}")
 
 
+def c2_batch(B=256, S=49, din=2048, T=20, V=10000, seed=1234):
+    """The bench workload's batch: features ~N(0,1), synthetic ids."""
+    gen = torch.Generator().manual_seed(seed)
+    features = torch.randn(B, S, din, generator=gen)
+    return features, synthetic_captions(B, T, V, gen)
+
+
+def gen_c2_shape():
+    """Full bench size (B=256): too big to commit whole, so 64 sampled logit rows, the loss, the global
+    and per-parameter gradient norms.  Weights are not stored: seed 42 + OracleCaptionDecoder init is
+    deterministic on CPU, the test rebuilds them the same way."""
+    torch.manual_seed(42)
+    model = OracleCaptionDecoder(vocab_size=10000, d_model=512, nhead=8, num_decoder_layers=6, feature_dim=2048)
+    model.eval()
+    features, ids = c2_batch()
+    logits = model(features, ids[:, :-1])
+    loss = label_smoothed_loss(logits, ids[:, 1:])
+    loss.backward()
+    names = [n for n, _ in model.named_parameters()]
+    norms = np.array([float(p.grad.double().pow(2).sum().sqrt()) for _, p in model.named_parameters()])
+    gn = float(np.sqrt((norms ** 2).sum()))
+    rows = torch.randperm(logits.shape[0] * logits.shape[1], generator=torch.Generator().manual_seed(7))[:64]
+    flat = logits.detach().reshape(-1, logits.shape[-1])
+    np.savez_compressed(f"{OUT}/c2_shape.npz", rows=rows.numpy(), logit_rows=flat[rows].numpy(),
+                        loss=loss.detach().numpy(), grad_norm=np.float64(gn), param_names=np.array(names),
+                        param_grad_norms=norms, weight_checksum=np.float64(sum(float(p.detach().double().sum()) for p in model.parameters())))
+    print(f"c2 shape: loss {loss.item():.6f} grad-norm {gn:.6f}")
+
+
 def gen_decode():
     out = {}
     for S in (1, 5):
@@ -160,7 +191,7 @@ def gen_decode():
 def main():
     os.makedirs(OUT, exist_ok=True)
     torch.set_num_threads(8)
-    which = sys.argv[1:] or ["vocab", "tiny", "c1", "decode"]
+    which = sys.argv[1:] or ["vocab", "tiny", "c1", "c2", "decode"]
     if "vocab" in which:
         gen_vocab_and_captions()
     if "tiny" in which:
@@ -168,6 +199,8 @@ def main():
         gen_tiny(5)
     if "c1" in which:
         gen_c1_shape()
+    if "c2" in which:
+        gen_c2_shape()
     if "decode" in which:
         gen_decode()
 

@@ -81,14 +81,16 @@ def cpu_baseline(cfg, steps=2):
 
 
 def decode_bench(model, cfg, dev, rank, world, dtype="fp32", images=1024, max_len=20):
-    """Beam-3 / beam-5 / greedy captions/s, KV-cached engine, images sharded per rank, no collective."""
+    """Beam-3 / beam-5 / greedy / reference-sampler captions/s, KV-cached engine, images sharded per rank, no collective."""
     from imagecaption_amd.decode import CaptionDecoder
     dec = CaptionDecoder(model, dtype=dtype)
     feats, _ = synth_batch(cfg, images, dev, 100 + rank)
     res = {}
     for name, fn in (("beam3", lambda: dec.beam(feats, beam=3, max_len=max_len)),
                      ("beam5", lambda: dec.beam(feats, beam=5, max_len=max_len)),
-                     ("greedy", lambda: dec.greedy(feats, max_len=max_len))):
+                     ("greedy", lambda: dec.greedy(feats, max_len=max_len)),
+                     # the reference's own decode (train.py:289-412: temperature 0.7, top-5 draw, sentence rules)
+                     ("sampler", lambda: dec.sample(feats, max_len=max_len + 1, seed=1))):
         fn()
         if world > 1:
             dist.barrier()

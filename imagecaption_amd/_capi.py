@@ -48,6 +48,7 @@ SIGNATURES = {
     "capdec_decode_attn": (_i, [_vp, _i, _vp, _vp, _i, _vp, _i, _vp, _i, _i, _i, _i, _i, _i, _i, _f, _vp]),
     "capdec_greedy_select": (_i, [_vp, _i, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _vp]),
     "capdec_beam_select": (_i, [_vp, _i, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _vp]),
+    "capdec_sample_select": (_i, [_vp, _i, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _i, _f, _u64, _vp]),
     "capdec_pe_add": (_i, [_vp, _vp, _vp, _i, _i, _i, _i, _i, _f, _u64, _vp]),
     "capdec_act_dropout_bwd": (_i, [_vp, _vp, _vp, _sz, _f, _u64, _vp]),
 }

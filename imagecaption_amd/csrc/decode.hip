@@ -233,7 +233,104 @@ __global__ __launch_bounds__(256) void beam_select_kernel(const float* __restric
     if (tid == 0 && gap && picked[W].s > NEG * 0.5f) gap[n] = fminf(gap[n], picked[W - 1].s - picked[W].s);
 }
 
+// ---- the reference's sampling step (ref train.py:335-383) on device --------------------------------
+// One block per row.  step i: forced END for the last two steps; otherwise logits / temperature, the
+// period (id 4) / END (id 2) biases driven by the per-row sentence counters, top-5 (ties -> lowest id),
+// and one draw from the top-5 weights by inverse CDF on a counter-based uniform (the reference's
+// torch.multinomial: same distribution, different stream).  Rows keep sampling after END exactly as the
+// reference does; the loop-level stop (all rows END in one step, or all rows at max_sentences,
+// train.py:383) is recorded in per-step counters that later steps read, so nothing syncs with the host.
+struct SampleParams {
+    const float* logits; int ldl;
+    int* words_since_period; int* sentences; int* seq; int64_t* next_tok;
+    int* cnt_end; int* cnt_max;  // [max_len] each, zeroed by the caller before step 0
+    int R, V, Tmax, i, max_len, max_sentences, min_words, late;
+    float temperature;
+    uint32_t s1, s2;
+};
+
+constexpr int SAMPLE_K = 5;
+
+__global__ __launch_bounds__(256) void sample_select_kernel(SampleParams p) {
+    __shared__ Cand sh[4];
+    __shared__ int stop_sh;
+    const int r = blockIdx.x, tid = threadIdx.x;
+    if (tid == 0) stop_sh = 0;
+    __syncthreads();
+    for (int j = tid; j < p.i; j += 256)
+        if (p.cnt_end[j] == p.R || p.cnt_max[j] == p.R) stop_sh = 1;  // benign race: every writer stores 1
+    __syncthreads();
+    if (stop_sh) return;  // the reference's loop has already ended (train.py:383-384)
+
+    const int wsp = p.words_since_period[r], sg = p.sentences[r];
+    int tok;
+    if (p.i >= p.max_len - 3) {  // train.py:335-336
+        tok = TOK_END;
+    } else {
+        const float* z = p.logits + (size_t)r * p.ldl;
+        auto biased = [&](int v) -> float {  // train.py:340-360, same order of additions
+            float l = z[v] / p.temperature;
+            if (v == 4) {
+                if (wsp < p.min_words) l = -INFINITY;
+                else l += 1.0f;
+                if (p.late) l += 2.0f;
+            } else if (v == TOK_END) {
+                if (sg >= p.max_sentences - 1 && wsp >= p.min_words) l += 2.0f;
+                if (p.late && wsp >= p.min_words) l += 3.0f;
+            }
+            return l;
+        };
+        Cand top[SAMPLE_K];
+#pragma unroll
+        for (int k = 0; k < SAMPLE_K; ++k) {
+            Cand c{-INFINITY, 0x7fffffff};
+            for (int v = tid; v < p.V; v += 256) {
+                bool taken = false;
+#pragma unroll
+                for (int q = 0; q < SAMPLE_K; ++q) taken |= (q < k) && (top[q].i == v);
+                if (taken) continue;
+                const Cand d{biased(v), v};  // -inf candidates stay eligible (ties -> lowest id)
+                if (better(d, c)) c = d;
+            }
+            top[k] = block_best(c, sh);
+            __syncthreads();
+        }
+        // weights exp(l - l_top) stand in for the top-5 probabilities (the softmax normaliser cancels)
+        float w[SAMPLE_K], total = 0.f;
+#pragma unroll
+        for (int k = 0; k < SAMPLE_K; ++k) {
+            w[k] = (top[k].i < p.V) ? expf(top[k].s - top[0].s) : 0.f;
+            total = k == 0 ? w[0] : total + w[k];
+        }
+        const uint32_t h = mix32(mix32((uint32_t)r + p.s1) ^ p.s2 ^ ((uint32_t)p.i * 0x9E3779B9u));
+        const float target = ((float)(h >> 8) * (1.0f / 16777216.0f)) * total;
+        int pick = SAMPLE_K - 1;
+#pragma unroll
+        for (int k = SAMPLE_K - 1; k >= 0; --k) {  // first k (ascending) with cum_k > target
+            float ck = 0.f;
+            for (int q = 0; q <= k; ++q) ck += w[q];
+            if (ck > target) pick = k;
+        }
+        tok = top[pick].i < p.V ? top[pick].i : top[0].i;
+    }
+    if (tid == 0) {
+        p.seq[(size_t)r * p.Tmax + p.i + 1] = tok;
+        p.next_tok[r] = tok;
+        int nsg = sg;
+        if (tok == 4) {  // train.py:374-380
+            nsg = sg + 1;
+            p.sentences[r] = nsg;
+            p.words_since_period[r] = 0;
+        } else if (tok > 4) {
+            p.words_since_period[r] = wsp + 1;
+        }
+        if (tok == TOK_END) atomicAdd(&p.cnt_end[p.i], 1);
+        if (nsg >= p.max_sentences) atomicAdd(&p.cnt_max[p.i], 1);
+    }
+}
+
 }  // namespace capdec
+
 
 using namespace capdec;
 
@@ -279,4 +376,25 @@ extern "C" int capdec_beam_select(const void* logits, int ldl, const void* score
                        (const float*)score_in, (float*)score_out, fin_in, fin_out, anc_in, anc_out, seq_in, seq_out,
                        next_tok, (float*)gap, W, V, Tmax, t);
     return check_launch("capdec_beam_select");
+}
+
+extern "C" int capdec_sample_select(const void* logits, int ldl, int* words_since_period, int* sentences, int* seq,
+                                    int64_t* next_tok, int* cnt_end, int* cnt_max, int R, int V, int Tmax, int i,
+                                    int max_len, int max_sentences, int min_words, float temperature, uint64_t seed,
+                                    capdec_stream_t stream) {
+    CAPDEC_REQUIRE(logits && words_since_period && sentences && seq && next_tok && cnt_end && cnt_max,
+                   "capdec_sample_select: null argument");
+    CAPDEC_REQUIRE(R > 0 && V > 4 && ldl >= V && i >= 0 && i + 1 < Tmax && max_len <= Tmax && i < max_len - 1 &&
+                       temperature > 0.f,
+                   "capdec_sample_select: bad shape (R=%d V=%d i=%d Tmax=%d max_len=%d)", R, V, i, Tmax, max_len);
+    SampleParams p;
+    p.logits = (const float*)logits; p.ldl = ldl;
+    p.words_since_period = words_since_period; p.sentences = sentences; p.seq = seq; p.next_tok = next_tok;
+    p.cnt_end = cnt_end; p.cnt_max = cnt_max;
+    p.R = R; p.V = V; p.Tmax = Tmax; p.i = i; p.max_len = max_len; p.max_sentences = max_sentences; p.min_words = min_words;
+    p.late = ((double)i >= (double)max_len * 0.9) ? 1 : 0;  // train.py:357, Python float comparison
+    p.temperature = temperature;
+    p.s1 = (uint32_t)seed; p.s2 = (uint32_t)(seed >> 32);
+    hipLaunchKernelGGL(sample_select_kernel, dim3(R), dim3(256), 0, (hipStream_t)stream, p);
+    return check_launch("capdec_sample_select");
 }

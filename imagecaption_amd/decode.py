@@ -12,6 +12,10 @@ This engine runs one token per step:
   attention kernel follows (csrc/decode.hip);
 * nothing synchronises with the host inside the loop (finished rows keep emitting PAD).
 
+``sample`` / ``generate_caption`` are the reference's own sampling decode (train.py:289-412) on this
+engine: the per-row sentence counters, logit biases, top-5 draw and the loop's stop rule run in one
+kernel per step (csrc/decode.hip sample_select_kernel) instead of ``B`` ``.item()`` syncs per step.
+
 Greedy and beam search are new capabilities (the reference only samples); their
 definition and oracle is ``oracle/torch_oracle.py``: START first, ties to the lowest index, END
 freezes a hypothesis (it then proposes only PAD at unchanged score), no length normalisation.
@@ -137,3 +141,62 @@ class CaptionDecoder:
         ids = st["seq"][cur].to(torch.int64).view(N, beam, max_len)
         out = (ids, score[cur])
         return out + (gap,) if return_gap else out
+
+    @torch.no_grad()
+    def sample(self, features, max_len=200, max_sentences=10, min_words_per_sentence=5, temperature=0.7, seed=0,
+               check_every=16):
+        """The reference's ``generate_caption`` (train.py:289-412) from projected-ViT ``features``:
+        ids ``[B, L]`` int64, START first, 0-padded, every row closed with ('.' if a sentence is open) END.
+        Same distribution as the reference (torch.multinomial is replaced by inverse-CDF sampling on a
+        counter-based uniform keyed by (seed, step, row)); token-exact against
+        ``oracle.torch_oracle.reference_sampler`` fed the same uniforms.  The host looks at the stop
+        counters every ``check_every`` steps only."""
+        st = self._prepare(features, 1, max_len)
+        R, dev = st["R"], features.device
+        tok = torch.full((R,), START, dtype=torch.int64, device=dev)
+        seq = st["seq"][0]
+        seq[:, 0] = START
+        wsp = torch.zeros(R, dtype=torch.int32, device=dev)
+        sg = torch.zeros(R, dtype=torch.int32, device=dev)
+        cnt = torch.zeros((2, max_len), dtype=torch.int32, device=dev)
+        l = lib()
+        steps = max_len - 1
+        for i in range(steps):
+            with ops.compute_dtype(self.dtype):
+                logits = self._step(tok, i, st)
+            check(l.capdec_sample_select(ptr(logits), logits.stride(0), ptr(wsp), ptr(sg), ptr(seq), ptr(tok), ptr(cnt[0]),
+                                         ptr(cnt[1]), R, self.V, max_len, i, max_len, max_sentences,
+                                         min_words_per_sentence, float(temperature), int(seed) & 0xFFFFFFFFFFFFFFFF,
+                                         stream()), "capdec_sample_select")
+            if (i + 1) % check_every == 0 and bool((cnt[:, :i + 1] == R).any()):
+                break
+        stop = (cnt == R).any(0).nonzero()
+        L = int(stop[0]) + 2 if stop.numel() else max_len  # START + (first stopping step + 1) tokens
+        gen = seq[:, :L].to(torch.int64)
+        # train.py:387-410: close open rows with ['.'] END, pad with 0 to the longest
+        need = gen[:, -1] != 2
+        add_p = need & (wsp > 0)
+        out = torch.zeros((R, L + 2), dtype=torch.int64, device=dev)
+        out[:, :L] = gen
+        rows = torch.arange(R, device=dev)
+        out[rows[add_p], L] = 4
+        end_pos = L + add_p.to(torch.int64)
+        out[rows[need], end_pos[need]] = 2
+        width = L + int((need.to(torch.int64) * (1 + add_p.to(torch.int64))).max())
+        return out[:, :width]
+
+
+def generate_caption(model, image, device, vocab_idx2word=None, max_len=200, max_sentences=10,
+                     min_words_per_sentence=5, seed=0, dtype="fp32"):
+    """Drop-in for the reference's ``generate_caption`` (train.py:289; same signature plus ``seed`` /
+    ``dtype``): ``model.vit(image)`` features -> KV-cached device sampler.  ``device`` and
+    ``vocab_idx2word`` are accepted for signature compatibility (the reference ignores the latter too)."""
+    model.eval()
+    with torch.no_grad():
+        features = model.vit(image)
+    dec = getattr(model, "_capdec_decoder", None)
+    if dec is None or dec.dtype != dtype:
+        dec = CaptionDecoder(model, dtype=dtype)
+        object.__setattr__(model, "_capdec_decoder", dec)
+    return dec.sample(features, max_len=max_len, max_sentences=max_sentences,
+                      min_words_per_sentence=min_words_per_sentence, seed=seed)

@@ -175,6 +175,19 @@ int capdec_beam_select(const void* logits, int ldl, const void* score_in, void* 
                        int* fin_out, const int* anc_in, int* anc_out, const int* seq_in, int* seq_out,
                        int64_t* next_tok, void* gap, int N, int W, int V, int Tmax, int t, capdec_stream_t stream);
 
+/* capdec_sample_select: one step of the reference's sampling decode (ref train.py:335-383) for R rows,
+ * without the reference's per-sample host syncs: step i writes seq[r, i+1] = next_tok[r] = END for the
+ * last two steps (i >= max_len-3), otherwise a draw from the top-5 of logits/temperature after the
+ * period (id 4) / END (id 2) biases of train.py:343-360, and updates words_since_period / sentences
+ * (train.py:374-380).  The draw replaces torch.multinomial by inverse CDF on the counter-based uniform
+ * (mix32(mix32(r + lo32(seed)) ^ hi32(seed) ^ i*0x9E3779B9) >> 8) / 2^24: same distribution.  cnt_end[i] /
+ * cnt_max[i] count the rows that emitted END / reached max_sentences in step i (zero both arrays,
+ * [max_len] ints, before step 0); once a step has all R rows in either, later calls do nothing -- the
+ * reference's break at train.py:383. */
+int capdec_sample_select(const void* logits, int ldl, int* words_since_period, int* sentences, int* seq,
+                         int64_t* next_tok, int* cnt_end, int* cnt_max, int R, int V, int Tmax, int i, int max_len,
+                         int max_sentences, int min_words, float temperature, uint64_t seed, capdec_stream_t stream);
+
 /* ---- elementwise helpers for the sub-module-at-a-time call path ---------------------------------
  * capdec_pe_add: out[r,:] = dropout(x[r,:] + pe[t0 + (r/div)%mod, :]) over x viewed as [R,d]
  *   (seq-first [T,B,d]: div=B, mod=T -- PositionalEncoding.forward, ref models.py:17-19).

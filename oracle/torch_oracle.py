@@ -205,3 +205,109 @@ def synthetic_captions(B, T, V, gen, min_len=8):
     ids = torch.where(pos == lens.unsqueeze(1), torch.full_like(ids, END), ids)
     ids = torch.where(pos > lens.unsqueeze(1), torch.full_like(ids, PAD), ids)
     return ids
+
+
+# ---------------------------------------------------------------------------------------------
+# Reference sampler: train.py:289-412 restated with the ONE
+# non-reproducible call, torch.multinomial(top_probs) at train.py:367, replaced by inverse-CDF
+# sampling on caller-supplied uniforms u[i, b] (same distribution: index j with probability
+# top_probs[j] / sum(top_probs)).  Everything else follows the reference line by line, including
+# its quirks: rows keep sampling after they emit END, the loop stops only when ALL rows emit END in
+# the same step or ALL rows reached max_sentences, the last two steps force END.
+def _mix32(x):
+    x &= 0xFFFFFFFF
+    x ^= x >> 16
+    x = (x * 0x7FEB352D) & 0xFFFFFFFF
+    x ^= x >> 15
+    x = (x * 0x846CA68B) & 0xFFFFFFFF
+    x ^= x >> 16
+    return x
+
+
+def sampler_uniforms(seed, steps, rows):
+    """The device sampler's counter-based uniforms (csrc/decode.hip sample_select_kernel):
+    u[i, b] = (mix32(mix32(b + lo32(seed)) ^ hi32(seed) ^ (i * 0x9E3779B9)) >> 8) / 2^24."""
+    lo, hi = seed & 0xFFFFFFFF, (seed >> 32) & 0xFFFFFFFF
+    u = torch.empty(steps, rows, dtype=torch.float32)
+    for i in range(steps):
+        for b in range(rows):
+            h = _mix32(_mix32((b + lo) & 0xFFFFFFFF) ^ hi ^ ((i * 0x9E3779B9) & 0xFFFFFFFF))
+            u[i, b] = (h >> 8) / 16777216.0
+    return u
+
+
+@torch.no_grad()
+def reference_sampler(model, features, uniforms, max_len=200, max_sentences=10, min_words_per_sentence=5):
+    """train.py:289-412 on projected features.  Returns (ids [B, L] int64 0-padded, min_margin) where
+    min_margin is the smallest relative distance of a draw from a CDF boundary (a draw that close to a
+    boundary may legitimately flip under 1-ulp differences of exp)."""
+    model.eval()
+    memory = model.project(features)  # train.py:294-300
+    B = features.size(0)
+    generated = torch.full((B, 1), 1, dtype=torch.long)  # train.py:304
+    words_since_period = torch.zeros(B, dtype=torch.long)  # train.py:309
+    sentences_generated = torch.zeros(B, dtype=torch.long)  # train.py:310
+    min_margin = float("inf")
+    for i in range(max_len - 1):  # train.py:312
+        output = model.decode(memory, generated)  # train.py:314-332
+        if i >= max_len - 3:  # train.py:335-336
+            next_token = torch.full((B, 1), 2, dtype=torch.long)
+        else:
+            temperature = 0.7
+            logits = output[:, -1:] / temperature  # train.py:340
+            for b in range(B):  # train.py:343-360
+                if words_since_period[b] < min_words_per_sentence:
+                    logits[b, :, 4] = float("-inf")
+                elif words_since_period[b] >= min_words_per_sentence:
+                    logits[b, :, 4] += 1.0
+                if sentences_generated[b] >= max_sentences - 1 and words_since_period[b] >= min_words_per_sentence:
+                    logits[b, :, 2] += 2.0
+                if i >= max_len * 0.9:
+                    logits[b, :, 4] += 2.0
+                    if words_since_period[b] >= min_words_per_sentence:
+                        logits[b, :, 2] += 3.0
+            # train.py:363-364: topk of softmax == the 5 largest logits (ties -> lowest index, stable sort);
+            # the normaliser cancels in the multinomial, so weights exp(l - max) stand in for top_probs
+            z = logits[:, 0, :]
+            order = torch.sort(z, dim=-1, descending=True, stable=True).indices[:, :5]
+            top = z.gather(1, order)
+            w = torch.exp(top - top[:, :1])
+            next_token = torch.empty(B, 1, dtype=torch.long)
+            for b in range(B):  # train.py:367-368 with inverse-CDF in place of multinomial
+                total = w[b, 0]
+                for j in range(1, 5):
+                    total = total + w[b, j]
+                target = uniforms[i, b] * total
+                cum = torch.zeros((), dtype=torch.float32)
+                pick = 4
+                for j in range(5):
+                    cum = cum + w[b, j]
+                    if j < 4:
+                        min_margin = min(min_margin, abs(float(cum - target)) / float(total))
+                    if cum > target:
+                        pick = j
+                        break
+                next_token[b, 0] = order[b, pick]
+        generated = torch.cat([generated, next_token], dim=1)  # train.py:371
+        for b in range(B):  # train.py:374-380
+            token_id = next_token[b].item()
+            if token_id == 4:
+                sentences_generated[b] += 1
+                words_since_period[b] = 0
+            elif token_id not in [0, 1, 2, 3, 4]:
+                words_since_period[b] += 1
+        if (next_token == 2).all() or (sentences_generated >= max_sentences).all():  # train.py:383
+            break
+    final = []
+    for b in range(B):  # train.py:387-396
+        seq = generated[b]
+        if seq[-1] != 2:
+            if words_since_period[b] > 0:
+                seq = torch.cat([seq, torch.tensor([4])])
+            seq = torch.cat([seq, torch.tensor([2])])
+        final.append(seq)
+    L = max(s.size(0) for s in final)  # train.py:399-410
+    out = torch.zeros(B, L, dtype=torch.long)
+    for b, s in enumerate(final):
+        out[b, :s.size(0)] = s
+    return out, min_margin

@@ -124,3 +124,83 @@ def test_bleu4_gate_reference_shape_greedy_vs_oracle():
     assert abs(100 * b_hip[1] - 100 * b_ref[1]) <= 0.1 and abs(100 * b_hip[0] - 100 * b_ref[0]) <= 0.1
     if gap > 1e-4:
         assert torch.equal(ids, ids_ref)
+
+
+# ---------------------------------------------------------------------------------------------
+# the reference's sampling decode (train.py:289-412) on the KV-cached engine
+def _sampler_models(bias_period=0.0, bias_end=0.0, S=1):
+    """Tiny oracle + product model with identical weights; optional output-bias boosts so that the
+    period / END rules of train.py:343-360 are actually exercised."""
+    from imagecaption_amd import ImageCaptioningModel
+    from oracle.torch_oracle import OracleCaptionDecoder
+    torch.manual_seed(42)
+    ref = OracleCaptionDecoder(**TINY)
+    with torch.no_grad():
+        ref.output_layer[3].weight.mul_(4.0)
+        ref.output_layer[3].bias[4] += bias_period
+        ref.output_layer[3].bias[2] += bias_end
+    model = ImageCaptioningModel(**TINY)
+    model.load_state_dict(ref.state_dict())
+    return ref.eval(), model.to(DEV).eval()
+
+
+@pytest.mark.parametrize("bias_period,bias_end,max_len,max_sentences,min_words", [
+    (0.0, 0.0, 24, 10, 5),      # never stops early: forced END in the last two steps
+    (6.0, 0.0, 60, 3, 2),       # sentences complete -> stop by max_sentences, rows closed with END
+    (5.0, 4.0, 40, 2, 1),       # END boosted once a row has enough sentences; late-phase boosts (i >= 0.9 max_len)
+])
+def test_reference_sampler_token_exact_given_the_same_uniforms(bias_period, bias_end, max_len, max_sentences, min_words):
+    from imagecaption_amd.decode import CaptionDecoder
+    from oracle.torch_oracle import reference_sampler, sampler_uniforms
+    ref, model = _sampler_models(bias_period, bias_end)
+    B, seed = 6, 0x1234ABCD5678
+    feats = torch.randn(B, TINY["feature_dim"], generator=torch.Generator().manual_seed(9))
+    u = sampler_uniforms(seed, max_len - 1, B)
+    want, margin = reference_sampler(ref, feats, u, max_len=max_len, max_sentences=max_sentences,
+                                     min_words_per_sentence=min_words)
+    got = CaptionDecoder(model).sample(feats.to(DEV), max_len=max_len, max_sentences=max_sentences,
+                                       min_words_per_sentence=min_words, seed=seed, check_every=4).cpu()
+    if margin < 1e-5:
+        pytest.skip(f"a draw sits {margin:.1e} from a CDF boundary: not decidable at fp32")
+    assert got.shape == want.shape, (got.shape, want.shape)
+    assert torch.equal(got, want)
+    assert (got[:, 0] == 1).all() and ((got == 2).sum(1) >= 1).all()
+
+
+def test_reference_sampler_memory_grid_and_generate_caption_signature():
+    """S=5 memory (the synthetic grid configs) and the drop-in generate_caption wrapper (train.py:289)."""
+    from imagecaption_amd.decode import CaptionDecoder, generate_caption
+    from oracle.torch_oracle import reference_sampler, sampler_uniforms
+    ref, model = _sampler_models(6.0, 2.0)
+    feats = torch.randn(4, 5, TINY["feature_dim"], generator=torch.Generator().manual_seed(10))
+    u = sampler_uniforms(77, 49, 4)
+    want, margin = reference_sampler(ref, feats, u, max_len=50, max_sentences=4, min_words_per_sentence=3)
+    got = CaptionDecoder(model).sample(feats.to(DEV), max_len=50, max_sentences=4, min_words_per_sentence=3, seed=77).cpu()
+    assert margin < 1e-5 or torch.equal(got, want)
+    model.vit = torch.nn.Identity()
+    out = generate_caption(model, feats[:, 0].to(DEV), DEV, None, max_len=30, max_sentences=2, min_words_per_sentence=2, seed=5)
+    assert out.dtype == torch.int64 and out.shape[0] == 4 and (out[:, 0] == 1).all()
+    for row in out.cpu().tolist():
+        body = [t for t in row if t != 0]
+        assert body[-1] == 2 and row[len(body):] == [0] * (len(row) - len(body))  # END-closed, then PAD only
+
+
+def test_sampler_draw_frequencies_follow_the_top5_distribution():
+    """Distribution-level check of the multinomial replacement: over many seeds the first sampled token's
+    frequencies match softmax(top-5 logits / 0.7) (chi-square, 4 dof, p ~ 1e-4 cut-off 23.5)."""
+    from imagecaption_amd.decode import CaptionDecoder
+    ref, model = _sampler_models()
+    feats = torch.randn(1, TINY["feature_dim"], generator=torch.Generator().manual_seed(3))
+    with torch.no_grad():
+        z = ref.decode(ref.project(feats), torch.tensor([[1]]))[0, -1] / 0.7
+    z[4] = float("-inf")  # words_since_period = 0 < min_words
+    top = torch.topk(z, 5)
+    probs = torch.softmax(top.values, 0).double()
+    dec = CaptionDecoder(model)
+    n = 1200
+    rows = feats.repeat(n, 1).to(DEV)  # the uniform is keyed by (seed, step, row): n rows = n draws
+    ids = dec.sample(rows, max_len=6, seed=2024)[:, 1].cpu()
+    counts = torch.stack([(ids == int(t)).sum() for t in top.indices]).double()
+    assert int(counts.sum()) == n  # never outside the top-5
+    chi2 = float((((counts - n * probs) ** 2) / (n * probs)).sum())
+    assert chi2 < 23.5, (chi2, counts.tolist(), (n * probs).tolist())

@@ -137,5 +137,43 @@ class CaptionTrainer:
         self.optimizer_step()
         return loss
 
+    # ---- interchange with torch.optim.AdamW (checkpoint.py; ref train.py:485-495, main.py:140-142) ----------
+    def _as_torch_adamw(self):
+        return torch.optim.AdamW(self.model.parameters(), lr=self.lr, betas=tuple(self.betas), eps=self.eps,
+                                 weight_decay=self.wd)
+
+    def adamw_state_dict(self):
+        """The optimizer state in ``torch.optim.AdamW.state_dict()`` format over ``model.parameters()``."""
+        opt = self._as_torch_adamw()
+        if self.step_count > 0:
+            off = {id(p): o for p, o in self.flat.placed}
+            for p in self.model.parameters():
+                o, n = off[id(p)], p.numel()
+                opt.state[p] = {"step": torch.tensor(float(self.step_count)),
+                                "exp_avg": self.flat_m[o:o + n].view_as(p).clone(),
+                                "exp_avg_sq": self.flat_v[o:o + n].view_as(p).clone()}
+        return opt.state_dict()
+
+    def load_adamw_state_dict(self, sd):
+        opt = self._as_torch_adamw()
+        opt.load_state_dict(sd)
+        g = opt.param_groups[0]
+        self.lr, self.betas, self.eps, self.wd = g["lr"], tuple(g["betas"]), g["eps"], g["weight_decay"]
+        off = {id(p): o for p, o in self.flat.placed}
+        self.flat_m.zero_()
+        self.flat_v.zero_()
+        steps = set()
+        for p in self.model.parameters():
+            st = opt.state.get(p)
+            if not st:
+                continue
+            o, n = off[id(p)], p.numel()
+            self.flat_m[o:o + n].view_as(p).copy_(st["exp_avg"])
+            self.flat_v[o:o + n].view_as(p).copy_(st["exp_avg_sq"])
+            steps.add(int(st["step"]))
+        if len(steps) > 1:
+            raise RuntimeError(f"CaptionTrainer keeps one step counter; the state has {sorted(steps)}")
+        self.step_count = steps.pop() if steps else 0
+
     def grad_norm(self):
         return self.gnorm_sq.sqrt()

@@ -173,6 +173,9 @@ def main():
     ap.add_argument("--decode-images", type=int, default=1024, help="images per GPU for the decode leg")
     ap.add_argument("--detail", action="store_true", help="print the per-shape kernel table to stderr")
     args = ap.parse_args()
+    if os.environ.get("CAPDEC_HANG_DUMP"):  # debugging aid: dump every thread's stack after N seconds and exit
+        import faulthandler
+        faulthandler.dump_traceback_later(int(os.environ["CAPDEC_HANG_DUMP"]), exit=True)
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))

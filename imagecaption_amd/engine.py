@@ -58,22 +58,7 @@ S_EMBED, S_PROJ, S_HEAD = 1000, 1001, 1002
 # ---------------------------------------------------------------------------------------------
 # decoder layer
 # ---------------------------------------------------------------------------------------------
-def cross_kv_ahead(layers, mem):
-    """With side lanes active: enqueue every layer's cross-attention K/V projection of the image
-    memory on lane 1 (they depend on nothing in the decoder chain).  Returns [(kv, ready_event)]."""
-    if ops.SIDE is None:
-        return None
-    out = []
-    for P in layers:
-        wc, bc = P["multihead_attn.in_proj_weight"], P["multihead_attn.in_proj_bias"]
-        d = wc.shape[1]
-        kv = torch.empty((mem.shape[0], 2 * d), dtype=torch.float32, device=mem.device)
-        ev = ops.SIDE.run(lambda: ops.linear_fwd(mem, wc[d:], bc[d:], out=kv), mem, kv, lane=1)
-        out.append((kv, ev))
-    return out
-
-
-def layer_fwd(P, x, mem, B, T, S, H, causal, dp, l, save, kv_ahead=None):
+def layer_fwd(P, x, mem, B, T, S, H, causal, dp, l, save):
     """x [B*T,d], mem [B*S,d] -> [B*T,d].  ``save`` (dict or None) receives what backward needs."""
     d = x.shape[1]
     p, sid = dp.p, 16 * l
@@ -85,11 +70,7 @@ def layer_fwd(P, x, mem, B, T, S, H, causal, dp, l, save, kv_ahead=None):
     x1, mean1, rstd1 = ops.layernorm_fwd(s1, P["norm1.weight"], P["norm1.bias"], save_stats=save is not None)
     wc, bc = P["multihead_attn.in_proj_weight"], P["multihead_attn.in_proj_bias"]
     q = ops.linear_fwd(x1, wc[:d], bc[:d])
-    if kv_ahead is not None:
-        kv, ready = kv_ahead
-        torch.cuda.current_stream().wait_event(ready)
-    else:
-        kv = ops.linear_fwd(mem, wc[d:], bc[d:])
+    kv = ops.linear_fwd(mem, wc[d:], bc[d:])
     c, lse2 = ops.attn_fwd(q, kv[:, :d], kv[:, d:], B, H, T, S, False, p, dp.seed(sid + S_CA_P),
                            save_lse=save is not None)
     s2 = ops.linear_fwd(c, P["multihead_attn.out_proj.weight"], P["multihead_attn.out_proj.bias"], drop_p=p,
@@ -134,15 +115,7 @@ def layer_bwd(P, G, sv, dx3, mem, dmem, B, T, S, H, causal, dp, l):
     gw, gb = G["multihead_attn.in_proj_weight"], G["multihead_attn.in_proj_bias"]
     ops.linear_wgrad(dq, sv["x1"], dw=gw[:d], db=gb[:d])
     ops.linear_wgrad(dkv, mem, dw=gw[d:], db=gb[d:])
-    if ops.SIDE is not None:
-        # d(memory) accumulates across layers on lane 1; nothing on the critical path reads it before proj_bwd
-        first = dmem is None
-        if first:
-            dmem = torch.empty((dkv.shape[0], d), dtype=torch.float32, device=dkv.device)
-        acc = dmem
-        ops.SIDE.run(lambda: ops.linear_dgrad(dkv, wc[d:], out=acc, addend=None if first else acc), dkv, lane=1)
-    else:
-        dmem = ops.linear_dgrad(dkv, wc[d:], addend=dmem)
+    dmem = ops.linear_dgrad(dkv, wc[d:], addend=dmem)
     dx1 = ops.linear_dgrad(dq, wc[:d], addend=g2)
     g1, g1m, _, _ = ops.layernorm_bwd(dx1, sv["s1"], P["norm1.weight"], P["norm1.bias"], sv["mean1"], sv["rstd1"],
                                       drop2_p=p, seed2=dp.seed(sid + S_SA_OUT), want_dx_drop=tr,
@@ -164,10 +137,9 @@ def layer_bwd(P, G, sv, dx3, mem, dmem, B, T, S, H, causal, dp, l):
 # ---------------------------------------------------------------------------------------------
 def stack_fwd(layers, norm_w, norm_b, x, mem, B, T, S, H, causal, dp, save):
     saves = [] if save is not None else None
-    ahead = cross_kv_ahead(layers, mem)
     for l, P in enumerate(layers):
         sv = {} if save is not None else None
-        x = layer_fwd(P, x, mem, B, T, S, H, causal, dp, l, sv, ahead[l] if ahead is not None else None)
+        x = layer_fwd(P, x, mem, B, T, S, H, causal, dp, l, sv)
         if saves is not None:
             saves.append(sv)
     y, mean, rstd = ops.layernorm_fwd(x, norm_w, norm_b, save_stats=save is not None)

@@ -37,50 +37,39 @@ class compute_dtype:
         COMPUTE_DTYPE = self.prev
 
 
-# Weight-gradient products may run on a side stream (trainer only): they depend on nothing later in
-# backward, so they fill the matrix pipes while the critical path runs its latency-bound kernels
-# (LayerNorm / attention backward, small input-gradient GEMMs with ragged tile counts).
 class SideStream:
-    """Side lanes for work that is off the critical path of a training step.
+    """One extra HIP stream for work that is off the critical path of a training step: the
+    weight-gradient GEMMs.  They depend on nothing later in backward, so they fill the matrix pipes
+    while the critical path runs its latency-bound kernels (LayerNorm / attention backward, small
+    input-gradient GEMMs with ragged tile counts).  The lane has its own split-K workspace; outputs are
+    always allocated by the caller on the main stream, so the caching allocator never sees a
+    cross-stream free.  (One lane only, on purpose: a process has 4 hardware queues, and the DP
+    reducer and RCCL need streams too; a second lane for the image-memory branch measured no gain.)"""
 
-    lane 0: weight-gradient GEMMs; lane 1: the image-memory branch (per-layer cross-attention K/V
-    projections in forward, the d(memory) accumulation chain in backward).  Each lane is one HIP
-    stream with its own split-K workspace; outputs are always allocated by the caller on the main
-    stream, so the caching allocator never sees a cross-stream free."""
-
-    def __init__(self, device, lanes=2):
-        self.streams = [torch.cuda.Stream(device=device) for _ in range(lanes)]
-        self.keep = []       # tensors a lane still reads; released at join()
+    def __init__(self, device):
+        self.stream = torch.cuda.Stream(device=device)
+        self.streams = (self.stream,)
+        self.keep = []       # tensors the lane still reads; released at join()
         self.pending = False
 
-    def run(self, fn, *tensors, lane=0):
-        """Enqueue fn() on the lane, ordered after everything enqueued so far on the current stream.
-        Returns an event recorded after it (main-stream consumers wait on it)."""
+    def run(self, fn, *tensors):
+        """Enqueue fn() on the lane, ordered after everything enqueued so far on the current stream."""
         global _WS_TAG
         ev = torch.cuda.Event()
         ev.record()
-        st = self.streams[lane]
-        st.wait_event(ev)
-        prev, _WS_TAG = _WS_TAG, f"side{lane}"
+        self.stream.wait_event(ev)
+        prev, _WS_TAG = _WS_TAG, "side"
         try:
-            with torch.cuda.stream(st):
+            with torch.cuda.stream(self.stream):
                 fn()
-                done = torch.cuda.Event()
-                done.record()
         finally:
             _WS_TAG = prev
         self.keep.extend(tensors)
         self.pending = True
-        return done
-
-    def wait_lane(self, lane):
-        torch.cuda.current_stream().wait_stream(self.streams[lane])
 
     def join(self):
         if self.pending:
-            cur = torch.cuda.current_stream()
-            for st in self.streams:
-                cur.wait_stream(st)
+            torch.cuda.current_stream().wait_stream(self.stream)
             self.keep.clear()
             self.pending = False
 

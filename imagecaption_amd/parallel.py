@@ -52,11 +52,21 @@ class BucketReducer:
     def __init__(self, flat_g, bucket_ranges, process_group=None, overlap=True):
         self.flat_g, self.ranges, self.pg = flat_g, bucket_ranges, process_group
         self.world = dist.get_world_size(process_group) if (dist.is_available() and dist.is_initialized()) else 1
-        self.side = torch.cuda.Stream(device=flat_g.device) if (overlap and self.world > 1 and flat_g.is_cuda) else None
-        self.works = []
+        # gloo on device tensors is a rehearsal vehicle only (tests, one-GPU dry runs of bench.py): its staged
+        # device collectives deadlock on this stack while the GPU is busy (reproduced with plain torch,
+        # tools/gloo_probe2.py), so that combination stages the buckets through host memory in finish().
+        self.serial = self.world > 1 and flat_g.is_cuda and dist.get_backend(process_group) == "gloo"
+        self.side = torch.cuda.Stream(device=flat_g.device) \
+            if (overlap and self.world > 1 and flat_g.is_cuda and not self.serial) else None
+        self.works, self.deferred = [], []
 
-    def reduce(self, idx):
+    def reduce(self, idx, after=()):
+        """``after``: extra streams whose enqueued work also writes this bucket (the trainer's
+        weight-gradient lanes); the collective is ordered behind them without stalling the caller."""
         if self.world == 1:
+            return
+        if self.serial:
+            self.deferred.append((idx, tuple(after)))
             return
         _, a, b = self.ranges[idx]
         buf = self.flat_g[a:b]
@@ -64,12 +74,24 @@ class BucketReducer:
             ev = torch.cuda.Event()
             ev.record()
             self.side.wait_event(ev)
+            for st in after:
+                self.side.wait_stream(st)
             with torch.cuda.stream(self.side):
                 self.works.append(dist.all_reduce(buf, op=dist.ReduceOp.SUM, group=self.pg, async_op=True))
         else:
+            for st in after:
+                torch.cuda.current_stream().wait_stream(st)
             self.works.append(dist.all_reduce(buf, op=dist.ReduceOp.SUM, group=self.pg, async_op=True))
 
     def finish(self):
+        for idx, after in self.deferred:
+            for st in after:
+                torch.cuda.current_stream().wait_stream(st)
+            _, a, b = self.ranges[idx]
+            host = self.flat_g[a:b].cpu()  # staged by hand: gloo's own device path is what deadlocks
+            dist.all_reduce(host, op=dist.ReduceOp.SUM, group=self.pg)
+            self.flat_g[a:b].copy_(host)
+        self.deferred = []
         for w in self.works:
             w.wait()
         self.works = []

@@ -105,24 +105,23 @@ class CaptionTrainer:
         nb = len(self.bucket_ranges)
         dy = engine.head_bwd(self.P_head, self.G_head, sv_head, dlogits, dp)
 
+        lanes = tuple(self.side.streams) if self.side is not None else ()
+
         def after_layer(l):
-            if self.side is not None and self.reducer.world > 1:
-                self.side.join()  # this layer's weight gradients must be complete before its bucket is reduced
+            # a bucket's collective waits for the weight-gradient lanes too; the critical path does not
             if l == self.nl - 1:
-                self.reducer.reduce(nb - 1)  # head + final norm are complete once layer L-1 started
-            self.reducer.reduce(1 + l)
+                self.reducer.reduce(nb - 1, after=lanes)  # head + final norm are complete once layer L-1 started
+            self.reducer.reduce(1 + l, after=lanes)
 
         dx, dmem = engine.stack_bwd(self.P_layers, self.G_layers, dec.norm.weight, dec.norm.bias, dec.norm.weight.grad,
                                     dec.norm.bias.grad, sv_stack, dy, mem, B, T, S, self.nhead, True, dp, after_layer)
-        if self.side is not None:
-            self.side.wait_lane(1)  # d(memory) is complete
         engine.proj_bwd(self.P_proj, self.G_proj, sv_proj, dmem, dp)
         ops.embed_bwd(tgt_in, dx.view(B, T, -1), m.embedding.weight.shape[0], dp.p, dp.seed(engine.S_EMBED),
                       dE=m.embedding.weight.grad)
+        self.reducer.reduce(0, after=lanes)
+        self.reducer.finish()
         if self.side is not None:
             self.side.join()
-        self.reducer.reduce(0)
-        self.reducer.finish()
         return loss, keep
 
     def optimizer_step(self):

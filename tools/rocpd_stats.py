@@ -5,6 +5,8 @@ db = sqlite3.connect(sys.argv[1])
 steps = int(sys.argv[2]) if len(sys.argv) > 2 else None
 cols = [r[1] for r in db.execute("pragma table_info(kernels)")]
 rows = db.execute("select name, start, end from kernels order by start").fetchall()
+by_grid = db.execute("select name, grid_x, grid_z, count(*), avg(end - start), min(end - start) from kernels "
+                     "where name like '%gemm_%' group by name, grid_x, grid_z order by sum(end - start) desc").fetchall()
 agg = {}
 for n, s, e in rows:
     a = agg.setdefault(n, [0, 0])
@@ -25,3 +27,9 @@ print(f"# {len(rows)} dispatches, sum of kernel durations {tot/1e6:.3f} ms, unio
 print(f"{'kernel':100s} {'calls':>7s} {'total_ms':>10s} {'avg_us':>9s} {'pct':>6s}")
 for n, (c, t) in sorted(agg.items(), key=lambda kv: -kv[1][1]):
     print(f"{n[:100]:100s} {c:7d} {t/1e6:10.3f} {t/c/1e3:9.2f} {100*t/tot:6.2f}")
+print()
+print("# GEMM launches by (kernel, grid): the vocab-projection forward is gemm_f32_kernel<128,64,..,NT> with grid_x = 40*157*256")
+print(f"{'kernel':72s} {'grid_x':>9s} {'gz':>3s} {'calls':>6s} {'avg_us':>9s} {'min_us':>9s}")
+for n, gx, gz, c, avg, mn in by_grid[:40]:
+    short = n.replace("void capdec::", "").replace("(capdec::GemmParams)", "")
+    print(f"{short[:72]:72s} {gx:9d} {gz:3d} {c:6d} {avg/1e3:9.2f} {mn/1e3:9.2f}")

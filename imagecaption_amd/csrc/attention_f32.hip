@@ -416,6 +416,72 @@ __global__ __launch_bounds__(64) void attn_bwd_dkv_kernel(AttnParams p) {
     }
 }
 
+// ---- Tk == 1 (the reference's own configuration: the memory is ONE projected ViT vector, ref
+// models.py:104): softmax over a single key is exactly 1 whatever the score, so
+//   out[b,t,h,:] = dropmask(b,h,t) * v[b,h,:],   dq = dk = 0 exactly,   dv[b,h,:] = sum_t dropmask * dout[b,t,h,:]
+// (torch computes the same exact zeros: p * (g - sum(p g)) with p = 1).  Streaming kernels instead of
+// 32 x 64 MFMA tiles that would be 1/64 full; same dropout element index as the general kernels.
+__global__ __launch_bounds__(256) void attn_s1_fwd_kernel(AttnParams p, int dh) {
+    const int c4 = p.H * dh / 4;  // float4 columns per row
+    const size_t idx = (size_t)blockIdx.x * 256 + threadIdx.x;
+    const size_t total = (size_t)p.B * p.Tq * c4;
+    const bool live = idx < total;
+    const int m = live ? (int)(idx / c4) : 0, c = live ? (int)(idx % c4) : 0;
+    const int b = m / p.Tq, t = m % p.Tq, h = (c * 4) / dh;
+    const int bh = b * p.H + h;
+    float part = 0.f;
+    if (live) {
+        float4 v4 = *reinterpret_cast<const float4*>(p.v + (size_t)b * p.ldv + c * 4);
+        if (p.drop.on()) {
+            const float w = p.drop.keep((uint32_t)bh * (uint32_t)p.Tq + (uint32_t)t) ? p.drop.scale : 0.f;
+            v4.x *= w; v4.y *= w; v4.z *= w; v4.w *= w;
+        }
+        *reinterpret_cast<float4*>(p.out + (size_t)m * p.ldo + c * 4) = v4;
+        if (p.lse) {
+            const float4 q4 = *reinterpret_cast<const float4*>(p.q + (size_t)m * p.ldq + c * 4);
+            const float4 k4 = *reinterpret_cast<const float4*>(p.k + (size_t)b * p.ldk + c * 4);
+            part = (q4.x * k4.x + q4.y * k4.y) + (q4.z * k4.z + q4.w * k4.w);
+        }
+    }
+    if (p.lse) {  // lse of one key = its scaled score; dh/4 consecutive lanes hold one head
+        for (int o = 1; o < dh / 4; o <<= 1) part += __shfl_xor(part, o, 64);
+        if (live && (c % (dh / 4)) == 0) p.lse[(size_t)bh * p.Tq + t] = part * p.scale;
+    }
+}
+
+// block = (b, 16 float4 columns) x 16 query lanes; fixed summation order (bitwise reproducible)
+__global__ __launch_bounds__(256) void attn_s1_bwd_kernel(AttnParams p, int dh) {
+    __shared__ float4 red[16][17];
+    const int c4 = p.H * dh / 4;
+    const int groups = c4 / 16;
+    const int b = blockIdx.x / groups, c = (blockIdx.x % groups) * 16 + (threadIdx.x & 15);
+    const int tl = threadIdx.x >> 4;
+    const int bh = b * p.H + (c * 4) / dh;
+    float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+    const float4 zero = make_float4(0.f, 0.f, 0.f, 0.f);
+    for (int t = tl; t < p.Tq; t += 16) {
+        const size_t m = (size_t)b * p.Tq + t;
+        float4 g = *reinterpret_cast<const float4*>(p.dout + m * p.lddo + c * 4);
+        if (p.drop.on()) {
+            const float w = p.drop.keep((uint32_t)bh * (uint32_t)p.Tq + (uint32_t)t) ? p.drop.scale : 0.f;
+            g.x *= w; g.y *= w; g.z *= w; g.w *= w;
+        }
+        acc.x += g.x; acc.y += g.y; acc.z += g.z; acc.w += g.w;
+        if (p.dq) *reinterpret_cast<float4*>(p.dq + m * p.lddq + c * 4) = zero;
+    }
+    red[tl][threadIdx.x & 15] = acc;
+    __syncthreads();
+    if (tl == 0) {
+        float4 s = red[0][threadIdx.x];
+        for (int j = 1; j < 16; ++j) {
+            const float4 a = red[j][threadIdx.x];
+            s.x += a.x; s.y += a.y; s.z += a.z; s.w += a.w;
+        }
+        *reinterpret_cast<float4*>(p.dv + (size_t)b * p.lddv + c * 4) = s;
+        *reinterpret_cast<float4*>(p.dk + (size_t)b * p.lddk + c * 4) = zero;
+    }
+}
+
 static int check_common(const char* what, int B, int H, int Tq, int Tk, int dh) {
     CAPDEC_REQUIRE(B > 0 && H > 0 && Tq > 0 && Tk > 0, "%s: bad shape B=%d H=%d Tq=%d Tk=%d", what, B, H, Tq, Tk);
     CAPDEC_REQUIRE(dh == 32 || dh == 64 || dh == 128, "%s: head dim %d not in {32,64,128}", what, dh);
@@ -442,6 +508,11 @@ extern "C" int capdec_attn_fwd(const void* q, int ldq, const void* k, int ldk, c
     p.drop = make_dropout(drop_p, drop_seed);
     const dim3 grid(B * H * ((Tq + 31) / 32));
     hipStream_t st = (hipStream_t)stream;
+    if (Tk == 1) {
+        const size_t total = (size_t)B * Tq * (H * dh / 4);
+        hipLaunchKernelGGL(attn_s1_fwd_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, st, p, dh);
+        return check_launch("capdec_attn_fwd");
+    }
     if (dh == 32) hipLaunchKernelGGL(attn_fwd_kernel<32>, grid, dim3(64), 0, st, p);
     else if (dh == 64) hipLaunchKernelGGL(attn_fwd_kernel<64>, grid, dim3(64), 0, st, p);
     else hipLaunchKernelGGL(attn_fwd_kernel<128>, grid, dim3(64), 0, st, p);
@@ -454,8 +525,8 @@ extern "C" int capdec_attn_bwd(const void* q, int ldq, const void* k, int ldk, c
                                float scale, float drop_p, uint64_t drop_seed, capdec_stream_t stream) {
     if (int rc = check_common("capdec_attn_bwd", B, H, Tq, Tk, dh)) return rc;
     CAPDEC_REQUIRE(ok_mat(q, ldq, H, dh) && ok_mat(k, ldk, H, dh) && ok_mat(v, ldv, H, dh) && ok_mat(o, ldo, H, dh) &&
-                       ok_mat(dout, lddo, H, dh) && ok_mat(dq, lddq, H, dh) && ok_mat(dk, lddk, H, dh) &&
-                       ok_mat(dv, lddv, H, dh) && lse && delta,
+                       ok_mat(dout, lddo, H, dh) && (ok_mat(dq, lddq, H, dh) || (Tk == 1 && !dq)) &&
+                       ok_mat(dk, lddk, H, dh) && ok_mat(dv, lddv, H, dh) && (Tk == 1 || (lse && delta)),
                    "capdec_attn_bwd: operands must be non-null, 16-byte aligned, ld %% 4 == 0, ld >= H*dh");
     AttnParams p;
     memset(&p, 0, sizeof(p));
@@ -466,6 +537,10 @@ extern "C" int capdec_attn_bwd(const void* q, int ldq, const void* k, int ldk, c
     p.B = B; p.H = H; p.Tq = Tq; p.Tk = Tk; p.causal = causal; p.scale = scale;
     p.drop = make_dropout(drop_p, drop_seed);
     hipStream_t st = (hipStream_t)stream;
+    if (Tk == 1) {
+        hipLaunchKernelGGL(attn_s1_bwd_kernel, dim3(B * (H * dh / 64)), dim3(256), 0, st, p, dh);
+        return check_launch("capdec_attn_bwd");
+    }
     const dim3 gq(B * H * ((Tq + 31) / 32)), gk(B * H * ((Tk + 31) / 32));
     if (dh == 32) {
         hipLaunchKernelGGL(attn_bwd_dq_kernel<32>, gq, dim3(64), 0, st, p);

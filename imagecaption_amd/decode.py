@@ -67,7 +67,7 @@ class CaptionDecoder:
             s1 = ops.linear_fwd(a, P["self_attn.out_proj.weight"], P["self_attn.out_proj.bias"], addend=x)
             x1, _, _ = ops.layernorm_fwd(s1, P["norm1.weight"], P["norm1.bias"], save_stats=False)
             wc, bc = P["multihead_attn.in_proj_weight"], P["multihead_attn.in_proj_bias"]
-            q = ops.linear_fwd(x1, wc[:d], bc[:d])
+            q = x1 if S == 1 else ops.linear_fwd(x1, wc[:d], bc[:d])  # one key: the query cannot matter
             kv = st["cross_kv"][li]  # [N*S, 2d]
             c = torch.empty((R, d), dtype=torch.float32, device=x.device)
             check(l.capdec_decode_attn(ptr(q), d, ptr(kv), ptr(kv[:, d:]), 2 * d, ptr(c), d, None, R, H, dh, Tmax, t, W,

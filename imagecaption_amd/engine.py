@@ -69,10 +69,12 @@ def layer_fwd(P, x, mem, B, T, S, H, causal, dp, l, save):
                         seed=dp.seed(sid + S_SA_OUT), addend=x)
     x1, mean1, rstd1 = ops.layernorm_fwd(s1, P["norm1.weight"], P["norm1.bias"], save_stats=save is not None)
     wc, bc = P["multihead_attn.in_proj_weight"], P["multihead_attn.in_proj_bias"]
-    q = ops.linear_fwd(x1, wc[:d], bc[:d])
+    # S == 1 (ref models.py:104): softmax over one key is 1 whatever the query, so the query projection
+    # cannot reach the output and its gradient is exactly zero -- it is skipped (x1 stands in as q)
+    q = x1 if S == 1 else ops.linear_fwd(x1, wc[:d], bc[:d])
     kv = ops.linear_fwd(mem, wc[d:], bc[d:])
     c, lse2 = ops.attn_fwd(q, kv[:, :d], kv[:, d:], B, H, T, S, False, p, dp.seed(sid + S_CA_P),
-                           save_lse=save is not None)
+                           save_lse=save is not None and S != 1)
     s2 = ops.linear_fwd(c, P["multihead_attn.out_proj.weight"], P["multihead_attn.out_proj.bias"], drop_p=p,
                         seed=dp.seed(sid + S_CA_OUT), addend=x1)
     x2, mean2, rstd2 = ops.layernorm_fwd(s2, P["norm2.weight"], P["norm2.bias"], save_stats=save is not None)
@@ -110,13 +112,17 @@ def layer_bwd(P, G, sv, dx3, mem, dmem, B, T, S, H, causal, dp, l):
     kv = sv["kv"]
     dkv = torch.empty_like(kv)
     dq, _, _ = ops.attn_bwd(sv["q"], kv[:, :d], kv[:, d:], sv["c"], dc, sv["lse2"], B, H, T, S, False, p,
-                            dp.seed(sid + S_CA_P), dk=dkv[:, :d], dv=dkv[:, d:])
+                            dp.seed(sid + S_CA_P), dk=dkv[:, :d], dv=dkv[:, d:], need_dq=S != 1)
     wc = P["multihead_attn.in_proj_weight"]
     gw, gb = G["multihead_attn.in_proj_weight"], G["multihead_attn.in_proj_bias"]
-    ops.linear_wgrad(dq, sv["x1"], dw=gw[:d], db=gb[:d])
+    if S == 1:  # dq == 0 exactly: zero query-projection gradients, nothing flows to x1 through q
+        gw[:d].zero_()
+        gb[:d].zero_()
+    else:
+        ops.linear_wgrad(dq, sv["x1"], dw=gw[:d], db=gb[:d])
     ops.linear_wgrad(dkv, mem, dw=gw[d:], db=gb[d:])
     dmem = ops.linear_dgrad(dkv, wc[d:], addend=dmem)
-    dx1 = ops.linear_dgrad(dq, wc[:d], addend=g2)
+    dx1 = g2 if S == 1 else ops.linear_dgrad(dq, wc[:d], addend=g2)
     g1, g1m, _, _ = ops.layernorm_bwd(dx1, sv["s1"], P["norm1.weight"], P["norm1.bias"], sv["mean1"], sv["rstd1"],
                                       drop2_p=p, seed2=dp.seed(sid + S_SA_OUT), want_dx_drop=tr,
                                       dgamma=G["norm1.weight"], dbeta=G["norm1.bias"])

@@ -250,11 +250,15 @@ def attn_fwd(q, k, v, B, H, Tq, Tk, causal, drop_p=0.0, seed=0, out=None, save_l
     return o, lse
 
 
-def attn_bwd(q, k, v, o, do, lse, B, H, Tq, Tk, causal, drop_p=0.0, seed=0, dq=None, dk=None, dv=None):
+def attn_bwd(q, k, v, o, do, lse, B, H, Tq, Tk, causal, drop_p=0.0, seed=0, dq=None, dk=None, dv=None, need_dq=True):
+    """``need_dq=False`` is accepted for Tk == 1 only (dq is exactly zero there and is then not written)."""
     D = q.shape[1]
     dh = D // H
     _mat(do, "attn_bwd.do")
-    dq = torch.empty((B * Tq, D), dtype=torch.float32, device=q.device) if dq is None else dq
+    if not need_dq and Tk != 1:
+        raise _capi.CapdecError("attn_bwd: need_dq=False requires Tk == 1")
+    if need_dq:
+        dq = torch.empty((B * Tq, D), dtype=torch.float32, device=q.device) if dq is None else dq
     dk = torch.empty((B * Tk, D), dtype=torch.float32, device=q.device) if dk is None else dk
     dv = torch.empty((B * Tk, D), dtype=torch.float32, device=q.device) if dv is None else dv
     delta = torch.empty((B, H, Tq), dtype=torch.float32, device=q.device)
@@ -262,7 +266,8 @@ def attn_bwd(q, k, v, o, do, lse, B, H, Tq, Tk, causal, drop_p=0.0, seed=0, dq=N
     with _Timed(f"attn_bwd_{'causal' if causal else 'cross'}_{Tq}x{Tk}", 10.0 * B * H * Tq * Tk * dh,
                 4.0 * B * D * (4 * Tq + 4 * Tk)):
         check(lib().capdec_attn_bwd(ptr(q), q.stride(0), ptr(k), k.stride(0), ptr(v), v.stride(0), ptr(o), o.stride(0),
-                                    ptr(do), do.stride(0), ptr(lse), ptr(delta), ptr(dq), dq.stride(0), ptr(dk),
+                                    ptr(do), do.stride(0), ptr(lse), ptr(delta), ptr(dq), dq.stride(0) if dq is not None else D,
+                                    ptr(dk),
                                     dk.stride(0), ptr(dv), dv.stride(0), B, H, Tq, Tk, dh, int(causal),
                                     1.0 / math.sqrt(dh), float(drop_p), int(seed), stream()), "capdec_attn_bwd")
     return dq, dk, dv

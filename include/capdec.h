@@ -110,6 +110,10 @@ int capdec_embed_bwd(const int64_t* ids, const void* dout, void* dE, int B, int 
  * causal: key tk is visible to query tq iff tk <= tq + (Tk - Tq).  dh in {32, 64, 128}.
  * bwd: dq, dk, dv from do, recomputing probabilities from lse (flash-style, no [Tq,Tk] tensor);
  *      delta [B,H,Tq] is scratch it fills (rowsum(do*o)).
+ * Tk == 1 (the reference's memory of one ViT vector, ref models.py:104): the softmax is exactly 1, so both
+ *      directions are streaming kernels: o = dropmask * v; dq = dk = 0 exactly (as torch computes them), dv =
+ *      sum_t dropmask * do.  There dq may be NULL (not written), and lse / delta are not needed by bwd
+ *      (lse, if given to fwd, still receives the scaled score; delta is left untouched).
  * Replaces torch/nn/functional.py:6386-6390, 6613-6631 (scaled_dot_product_attention inside
  * multi_head_attention_forward) for both the causal self-attention and the cross-attention over
  * the image memory (torch/nn/modules/transformer.py:1158-1194).

@@ -433,3 +433,33 @@ def test_gemm_f32x3_epilogue_and_wgrad():
     assert relerr(dw, dy.double().T @ xx.double()) < 2e-5
     assert relerr(db, dy.double().sum(0)) < 2e-5
     assert relerr(dx, dy.double() @ w.double()) < 1e-5
+
+
+@pytest.mark.parametrize("B,H,Tq,dh,p", [(3, 2, 7, 32, 0.0), (32, 8, 299, 64, 0.0), (2, 8, 20, 128, 0.0), (4, 8, 50, 64, 0.3)])
+def test_attention_single_key_streaming_path(B, H, Tq, dh, p):
+    """Tk == 1 (the reference's one-vector memory): out = dropmask * v, dq = dk = 0 exactly, dv = sum_t dropmask * do;
+    without dropout compared with torch SDPA, with dropout checked for fwd/bwd mask consistency and keep rate."""
+    ops = _ops()
+    g = torch.Generator().manual_seed(B + Tq)
+    D = H * dh
+    q, k, v = torch.randn(B * Tq, D, generator=g), torch.randn(B, D, generator=g), torch.randn(B, D, generator=g)
+    do = torch.randn(B * Tq, D, generator=g)
+    o, lse = ops.attn_fwd(q.to(DEV), k.to(DEV), v.to(DEV), B, H, Tq, 1, False, p, 99)
+    dq, dk, dv = ops.attn_bwd(q.to(DEV), k.to(DEV), v.to(DEV), o, do.to(DEV), lse, B, H, Tq, 1, False, p, 99)
+    _, dk2, dv2 = ops.attn_bwd(q.to(DEV), k.to(DEV), v.to(DEV), o, do.to(DEV), None, B, H, Tq, 1, False, p, 99, need_dq=False)
+    assert torch.equal(dv, dv2) and torch.equal(dk, dk2)
+    assert float(dq.abs().max()) == 0.0 and float(dk.abs().max()) == 0.0
+    ref_lse = (q.view(B, Tq, H, dh) * k.view(B, 1, H, dh)).sum(-1).permute(0, 2, 1) / math.sqrt(dh)
+    assert relerr(lse, ref_lse) < 1e-5
+    vb = v.view(B, 1, H, dh).expand(B, Tq, H, dh).reshape(B * Tq, D)
+    if p == 0.0:
+        assert torch.equal(o.cpu(), vb)
+        assert relerr(dv, do.view(B, Tq, D).double().sum(1)) < 1e-5
+    else:
+        mask = (o.cpu() != 0).view(B, Tq, H, dh)
+        assert (mask.all(-1) | (~mask).all(-1)).all()  # one decision per (b, t, head)
+        keep = mask.all(-1)
+        assert abs(float(keep.float().mean()) - (1 - p)) < 0.05
+        w = keep.unsqueeze(-1).float() / (1 - p)
+        assert relerr(o, (w * vb.view(B, Tq, H, dh)).reshape(B * Tq, D)) < 1e-6
+        assert relerr(dv, (w * do.view(B, Tq, H, dh)).double().sum(1).reshape(B, D)) < 1e-5

@@ -111,6 +111,24 @@ def decode_bench(model, cfg, dev, rank, world, dtype="fp32", images=1024, max_le
     return res
 
 
+def measured_mfma_peak(dtype):
+    """Sustained matrix rate of THIS box from a register-resident MFMA loop (csrc/probe.hip), TFLOP/s."""
+    import ctypes as C
+    from imagecaption_amd import _capi
+    from imagecaption_amd._capi import check, lib, ptr, stream
+    out = torch.zeros(16, device="cuda")
+    fl = C.c_double(0.0)
+    dt = _capi.F32 if dtype == "fp32" else _capi.BF16
+    check(lib().capdec_probe_mfma(dt, 2048, 200, ptr(out), C.byref(fl), stream()), "capdec_probe_mfma")
+    torch.cuda.synchronize()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    check(lib().capdec_probe_mfma(dt, 2048, 10000, ptr(out), C.byref(fl), stream()), "capdec_probe_mfma")
+    e1.record()
+    torch.cuda.synchronize()
+    return fl.value / (e0.elapsed_time(e1) * 1e-3) / 1e12
+
+
 def vocab_traffic(config):
     """HBM-side bytes per launch of the vocab GEMM from the committed PMC passes (profiles/), C2 only."""
     path = os.path.join(ROOT, "profiles", "r01_vocab_gemm_traffic.json")
@@ -261,7 +279,8 @@ def main():
                           "unit": "TFLOP/s", "frac": vocab[1] / vocab[3] / 1e12 / peak,
                           "traffic": vocab_traffic(args.config) if args.dtype == "fp32" else None,
                           "kernel": f"gemm_{'f32' if args.dtype == 'fp32' else 'bf16'}_kernel, vocab projection forward {vk[8:]} (one launch per step)",
-                          "ms": vocab[3] * 1e3 / vocab[0]} if vocab else None),
+                          "ms": vocab[3] * 1e3 / vocab[0],
+                          "peak_measured": measured_mfma_peak("fp32" if args.dtype == "fp32" else "bf16")} if vocab else None),
             "gemm_all": {"bound": "mfma", "achieved": ach, "peak": peak, "unit": "TFLOP/s",
                          "frac": ach / peak, "launches_per_step": gemm_n,
                          "ms_per_step": gemm_time * 1e3},

@@ -192,6 +192,12 @@ int capdec_sample_select(const void* logits, int ldl, int* words_since_period, i
                          int64_t* next_tok, int* cnt_end, int* cnt_max, int R, int V, int Tmax, int i, int max_len,
                          int max_sentences, int min_words, float temperature, uint64_t seed, capdec_stream_t stream);
 
+/* ---- peak probes (measurement only, no reference counterpart): a register-resident MFMA loop
+ * (dtype CAPDEC_F32: v_mfma_f32_32x32x2_f32, CAPDEC_BF16: v_mfma_f32_32x32x16_bf16; `blocks` workgroups of
+ * 4 waves, 4*iters MFMAs per wave; *flops receives the FLOPs issued) and a streaming copy of `bytes`. */
+int capdec_probe_mfma(int dtype, int blocks, int iters, void* out, double* flops, capdec_stream_t stream);
+int capdec_probe_copy(const void* src, void* dst, size_t bytes, capdec_stream_t stream);
+
 /* ---- elementwise helpers for the sub-module-at-a-time call path ---------------------------------
  * capdec_pe_add: out[r,:] = dropout(x[r,:] + pe[t0 + (r/div)%mod, :]) over x viewed as [R,d]
  *   (seq-first [T,B,d]: div=B, mod=T -- PositionalEncoding.forward, ref models.py:17-19).

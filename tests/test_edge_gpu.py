@@ -1,0 +1,118 @@
+"""Edge cases of the drop-in module and trainer against the live CPU oracle (tiny config): degenerate and
+ragged shapes, all-PAD targets, strided inputs, and the error behaviour at the limits."""
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda"
+TINY = dict(vocab_size=50, d_model=64, nhead=2, num_decoder_layers=2, feature_dim=24)
+
+
+def relerr(a, b):
+    a, b = torch.as_tensor(a).detach().double().cpu(), torch.as_tensor(b).detach().double().cpu()
+    return float((a - b).abs().max() / (b.abs().max() + 1e-30))
+
+
+def pair(seed=42):
+    from imagecaption_amd import ImageCaptioningModel
+    from oracle.torch_oracle import OracleCaptionDecoder
+    torch.manual_seed(seed)
+    ref = OracleCaptionDecoder(**TINY).eval()
+    model = ImageCaptioningModel(**TINY)
+    model.load_state_dict(ref.state_dict())
+    return ref, model.to(DEV).eval()
+
+
+def step_both(ref, model, feats, caps):
+    from imagecaption_amd.trainer import CaptionTrainer
+    from oracle.torch_oracle import label_smoothed_loss
+    logits_ref = ref(feats, caps[:, :-1])
+    loss_ref = label_smoothed_loss(logits_ref, caps[:, 1:])
+    ref.zero_grad()
+    loss_ref.backward()
+    tr = CaptionTrainer(model, dropout=0.0)
+    loss, logits = tr.forward_backward(feats.to(DEV), caps.to(DEV), train=False, keep_logits=True)
+    assert relerr(logits.view(logits_ref.shape), logits_ref) < 5e-5
+    assert abs(loss.item() - loss_ref.item()) < 2e-5 * abs(loss_ref.item())
+    gref = dict(ref.named_parameters())
+    for n, p in model.named_parameters():
+        g = gref[n].grad
+        scale = max(float(g.abs().max()), 1e-6)
+        assert float((p.grad.cpu() - g).abs().max()) < 3e-4 * scale + 1e-7, n
+
+
+@pytest.mark.parametrize("B,T,S", [(1, 1, 1), (1, 2, 3), (3, 33, 7), (2, 65, 1), (5, 31, 64), (1, 97, 65)])
+def test_ragged_and_degenerate_shapes_match_oracle(B, T, S):
+    ref, model = pair()
+    g = torch.Generator().manual_seed(B * 100 + T)
+    feats = torch.randn((B, 24) if S == 1 else (B, S, 24), generator=g)
+    caps = torch.randint(5, 50, (B, T + 1), generator=g)
+    caps[:, 0] = 1
+    step_both(ref, model, feats, caps)
+
+
+def test_all_pad_targets_and_repeated_tokens():
+    """PAD stays in the loss (ref train.py:41-50 has no ignore_index); one token id carrying every row is the
+    worst case of the embedding backward's ordered reduction."""
+    ref, model = pair()
+    g = torch.Generator().manual_seed(5)
+    feats = torch.randn(4, 5, 24, generator=g)
+    caps = torch.zeros(4, 41, dtype=torch.long)
+    caps[:, 0] = 1
+    step_both(ref, model, feats, caps)
+    caps = torch.full((4, 41), 49, dtype=torch.long)  # last vocabulary id everywhere
+    step_both(ref, model, feats, caps)
+
+
+def test_strided_and_non_contiguous_inputs():
+    ref, model = pair()
+    g = torch.Generator().manual_seed(6)
+    big_f = torch.randn(6, 5, 48, generator=g)
+    big_c = torch.randint(5, 50, (6, 40), generator=g)
+    feats, caps = big_f[::2, :, ::2], big_c[::2, ::2]  # views with strides in every dimension
+    mask = model.generate_square_subsequent_mask(caps.size(1) - 1).to(DEV)
+    out = model(feats.to(DEV)[:, :, :], caps.to(DEV)[:, :-1], mask)
+    assert relerr(out, ref(feats.contiguous(), caps[:, :-1].contiguous())) < 5e-5
+
+
+def test_limits_raise_runtime_errors_not_faults():
+    ref, model = pair()
+    feats = torch.randn(1, 24)
+    # longer than the positional table (ref models.py:8: max_len 5000): the reference fails to broadcast; so do we
+    caps = torch.ones(1, 5002, dtype=torch.long)
+    with pytest.raises(RuntimeError):
+        model(feats.to(DEV), caps.to(DEV), None)
+    # empty batch
+    with pytest.raises(RuntimeError):
+        model(torch.zeros(0, 24, device=DEV), torch.zeros(0, 4, dtype=torch.long, device=DEV), None)
+    # wrong feature width
+    with pytest.raises(RuntimeError):
+        model(torch.zeros(2, 25, device=DEV), torch.ones(2, 4, dtype=torch.long, device=DEV), None)
+    # CPU tensors: no fallback
+    with pytest.raises(RuntimeError):
+        model(feats, torch.ones(1, 4, dtype=torch.long), None)
+    # ids outside the vocabulary cannot fault the GPU: they are clamped (documented difference: torch raises)
+    bad = torch.tensor([[1, 49, 50, 10**9, -3]], device=DEV)
+    out = model(feats.to(DEV), bad, None)
+    assert torch.isfinite(out).all()
+    ok = torch.tensor([[1, 49, 49, 49, 0]], device=DEV)
+    assert torch.equal(out, model(feats.to(DEV), ok, None))
+
+
+def test_decode_edge_shapes():
+    from imagecaption_amd.decode import CaptionDecoder
+    from oracle.torch_oracle import beam_decode, greedy_decode
+    ref, model = pair()
+    with torch.no_grad():
+        ref.output_layer[3].weight.mul_(8.0)
+    model.load_state_dict(ref.state_dict())
+    dec = CaptionDecoder(model)
+    feats = torch.randn(1, 24, generator=torch.Generator().manual_seed(8))
+    ids, _ = greedy_decode(ref, feats, max_len=1)
+    assert torch.equal(dec.greedy(feats.to(DEV), max_len=1).cpu(), ids)
+    ids, sc, _ = beam_decode(ref, feats, beam=8, max_len=3)  # widest supported beam, single image
+    got, gsc = dec.beam(feats.to(DEV), beam=8, max_len=3)
+    assert torch.equal(got.cpu(), ids) and relerr(gsc, sc) < 1e-5
+    with pytest.raises(RuntimeError):
+        dec.beam(feats.to(DEV), beam=9, max_len=3)

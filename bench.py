@@ -202,7 +202,10 @@ def main():
     backend = os.environ.get("CAPDEC_DIST_BACKEND", "nccl")
     if os.environ.get("CAPDEC_SINGLE_DEVICE") == "1":
         local_rank = 0
-    if world > 1:
+    forced = os.environ.get("CAPDEC_FORCE_COLLECTIVES") == "1"  # one-rank group: exercises the RCCL path on 1 GPU
+    if forced and world == 1:
+        os.environ.setdefault("MASTER_PORT", "29555")
+    if world > 1 or forced:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         if backend == "nccl":
             dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
@@ -295,7 +298,7 @@ def main():
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(cfg)
         print(json.dumps(out), flush=True)
-    if world > 1:
+    if world > 1 or forced:
         dist.barrier()
         dist.destroy_process_group()
 

@@ -37,17 +37,38 @@ class compute_dtype:
         COMPUTE_DTYPE = self.prev
 
 
+# ---- streams ------------------------------------------------------------------------------------
+# HIP multiplexes all streams of one priority over 4 hardware queues by reference count, so two
+# normal-priority streams may share a queue (observed: once RCCL had created its streams the trainer's
+# side lane landed on the caller's queue and every overlap was gone).  High-priority streams draw from
+# their own queue pool.  The trainer therefore runs its step on TWO high-priority streams of its own --
+# slot 0 the critical path, slot 1 the weight-gradient lane -- which cannot share a queue with the
+# caller's stream, the DP reducer's stream or RCCL's (all normal priority).  Exactly two, shared by
+# every trainer of the process: on this ROCm stack the 4th high-priority stream of a process deadlocks
+# (tools/hp_stream_probe.py).
+_HP_STREAMS = {}
+
+
+def hp_stream(device, slot):
+    key = (torch.device(device).index if torch.device(device).index is not None else torch.cuda.current_device(), slot)
+    if key not in _HP_STREAMS:
+        for s in range(slot + 1):  # create in slot order so slot numbers match creation order
+            k = (key[0], s)
+            if k not in _HP_STREAMS:
+                _HP_STREAMS[k] = torch.cuda.Stream(device=key[0], priority=-1)
+    return _HP_STREAMS[key]
+
+
 class SideStream:
-    """One extra HIP stream for work that is off the critical path of a training step: the
-    weight-gradient GEMMs.  They depend on nothing later in backward, so they fill the matrix pipes
-    while the critical path runs its latency-bound kernels (LayerNorm / attention backward, small
-    input-gradient GEMMs with ragged tile counts).  The lane has its own split-K workspace; outputs are
-    always allocated by the caller on the main stream, so the caching allocator never sees a
-    cross-stream free.  (One lane only, on purpose: a process has 4 hardware queues, and the DP
-    reducer and RCCL need streams too; a second lane for the image-memory branch measured no gain.)"""
+    """The weight-gradient lane of a training step.  Weight-gradient GEMMs depend on nothing later in
+    backward, so they fill the matrix pipes while the critical path runs its latency-bound kernels
+    (LayerNorm / attention backward, small input-gradient GEMMs with ragged tile counts).  The lane has
+    its own split-K workspace; outputs are always allocated by the caller on the critical-path stream,
+    so the caching allocator never sees a cross-stream free."""
 
     def __init__(self, device):
-        self.stream = torch.cuda.Stream(device=device)
+        self.main = hp_stream(device, 0)
+        self.stream = hp_stream(device, 1)
         self.streams = (self.stream,)
         self.keep = []       # tensors the lane still reads; released at join()
         self.pending = False
@@ -72,6 +93,26 @@ class SideStream:
             torch.cuda.current_stream().wait_stream(self.stream)
             self.keep.clear()
             self.pending = False
+
+
+class on_stream:
+    """Run a block on ``stream`` between the caller's stream's past and future: the stream first waits for
+    everything the caller has enqueued, and the caller's stream waits for the block at exit."""
+
+    def __init__(self, stream):
+        self.stream = stream
+
+    def __enter__(self):
+        self.outer = torch.cuda.current_stream()
+        self.stream.wait_stream(self.outer)
+        self.ctx = torch.cuda.stream(self.stream)
+        self.ctx.__enter__()
+        return self
+
+    def __exit__(self, *exc):
+        self.ctx.__exit__(*exc)
+        self.outer.wait_stream(self.stream)
+        return False
 
 
 _WS_TAG = "main"

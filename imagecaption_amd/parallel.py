@@ -8,6 +8,8 @@ The reference has no distributed code at all; the one exch
 path is the gradient all-reduce(sum), placed after backward and BEFORE the global-norm clip
 (ref train.py:56) so every rank clips by the same global norm.
 """
+import os
+
 import torch
 import torch.distributed as dist
 
@@ -52,18 +54,22 @@ class BucketReducer:
     def __init__(self, flat_g, bucket_ranges, process_group=None, overlap=True):
         self.flat_g, self.ranges, self.pg = flat_g, bucket_ranges, process_group
         self.world = dist.get_world_size(process_group) if (dist.is_available() and dist.is_initialized()) else 1
+        # CAPDEC_FORCE_COLLECTIVES=1: issue the bucket collectives even in a one-rank group (a sum over one
+        # rank), so the RCCL + side-stream choreography can be exercised on a single GPU
+        self.active = self.world > 1 or (os.environ.get("CAPDEC_FORCE_COLLECTIVES") == "1" and dist.is_available()
+                                         and dist.is_initialized())
         # gloo on device tensors is a rehearsal vehicle only (tests, one-GPU dry runs of bench.py): its staged
         # device collectives deadlock on this stack while the GPU is busy (reproduced with plain torch,
         # tools/gloo_probe2.py), so that combination stages the buckets through host memory in finish().
-        self.serial = self.world > 1 and flat_g.is_cuda and dist.get_backend(process_group) == "gloo"
+        self.serial = self.active and flat_g.is_cuda and dist.get_backend(process_group) == "gloo"
         self.side = torch.cuda.Stream(device=flat_g.device) \
-            if (overlap and self.world > 1 and flat_g.is_cuda and not self.serial) else None
+            if (overlap and self.active and flat_g.is_cuda and not self.serial) else None
         self.works, self.deferred = [], []
 
     def reduce(self, idx, after=()):
         """``after``: extra streams whose enqueued work also writes this bucket (the trainer's
         weight-gradient lanes); the collective is ordered behind them without stalling the caller."""
-        if self.world == 1:
+        if not self.active:
             return
         if self.serial:
             self.deferred.append((idx, tuple(after)))

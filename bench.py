@@ -61,6 +61,18 @@ def train_flops_per_image(cfg):
     return 3.0 * fwd
 
 
+def decode_flops_per_image(cfg, W, T):
+    """SURVEY.md section 8d, KV-cached decode with W hypotheses for T steps, FLOPs = 2*MAC.  Once per image: the
+    memory projection and the L cross K/V projections.  Per hypothesis and step: per layer 28 d^2 of projections
+    (self qkv 6, self out 2, cross q 2, cross out 2, FFN 16), 4 S d of cross attention and ~4 (T/2) d of self
+    attention over the cache; then the head, 4 d^2 + 4 d V.  C2, W=5, T=20: 7.2 GFLOP per image."""
+    L, S, d, V, din = cfg["layers"], cfg["S"], cfg["d"], cfg["vocab"], cfg["din"]
+    once = S * (4 * din * d + 4 * d * d) + L * 4 * S * d * d
+    per_tok = L * (2 * d * 3 * d + 2 * d * d + 2 * d * d + 2 * d * d + 16 * d * d + 4 * S * d + 4 * (T / 2.0) * d) \
+        + (4 * d * d + 4 * d * V)
+    return once + W * T * per_tok
+
+
 def cpu_baseline(cfg, steps=2):
     """The reference's CPU path (stock torch.nn decoder, oracle/torch_oracle.py) on this box's host cores."""
     from oracle.torch_oracle import OracleCaptionDecoder, train_step
@@ -106,6 +118,10 @@ def decode_bench(model, cfg, dev, rank, world, dtype="fp32", images=1024, max_le
             dist.all_reduce(t, op=dist.ReduceOp.MAX)
             dt = float(t.item())
         res[f"{name}_captions_per_sec"] = images * world / dt
+        W = {"beam3": 3, "beam5": 5}.get(name, 1)
+        tf = decode_flops_per_image(cfg, W, max_len) * images / dt / 1e12  # per GPU (dt is the slowest rank's)
+        peak = PEAK_F32_MFMA_TFLOPS if dtype == "fp32" else PEAK_BF16_MFMA_TFLOPS
+        res[f"{name}_roofline"] = {"bound": "mfma", "achieved": tf, "peak": peak, "unit": "TFLOP/s", "frac": tf / peak}
     res["images_per_gpu"], res["max_len"] = images, max_len
     model.train()
     return res

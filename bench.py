@@ -92,7 +92,7 @@ def cpu_baseline(cfg, steps=2):
                       f"stock torch.nn fp32 on {threads} host threads, {dt:.2f} s/step"}
 
 
-def decode_bench(model, cfg, dev, rank, world, dtype="fp32", images=1024, max_len=20):
+def decode_bench(model, cfg, dev, rank, world, dtype="fp32", images=4096, max_len=20):
     """Beam-3 / beam-5 / greedy / reference-sampler captions/s, KV-cached engine, images sharded per rank, no collective."""
     from imagecaption_amd.decode import CaptionDecoder
     dec = CaptionDecoder(model, dtype=dtype)
@@ -101,6 +101,11 @@ def decode_bench(model, cfg, dev, rank, world, dtype="fp32", images=1024, max_le
     for name, fn in (("beam3", lambda: dec.beam(feats, beam=3, max_len=max_len)),
                      ("beam5", lambda: dec.beam(feats, beam=5, max_len=max_len)),
                      ("greedy", lambda: dec.greedy(feats, max_len=max_len)),
+                     # the same loops replayed from a captured hipGraph (measured: no gain at >= 1024 images,
+                     # the loop is GPU-bound there; kept behind CAPDEC_BENCH_GRAPH=1)
+                     *((("beam3_graph", lambda: dec.beam(feats, beam=3, max_len=max_len, use_graph=True)),
+                        ("greedy_graph", lambda: dec.greedy(feats, max_len=max_len, use_graph=True)))
+                       if os.environ.get("CAPDEC_BENCH_GRAPH") == "1" else ()),
                      # the reference's own decode (train.py:289-412: temperature 0.7, top-5 draw, sentence rules)
                      ("sampler", lambda: dec.sample(feats, max_len=max_len + 1, seed=1))):
         fn()
@@ -118,7 +123,7 @@ def decode_bench(model, cfg, dev, rank, world, dtype="fp32", images=1024, max_le
             dist.all_reduce(t, op=dist.ReduceOp.MAX)
             dt = float(t.item())
         res[f"{name}_captions_per_sec"] = images * world / dt
-        W = {"beam3": 3, "beam5": 5}.get(name, 1)
+        W = {"beam3": 3, "beam5": 5, "beam3_graph": 3}.get(name, 1)
         tf = decode_flops_per_image(cfg, W, max_len) * images / dt / 1e12  # per GPU (dt is the slowest rank's)
         peak = PEAK_F32_MFMA_TFLOPS if dtype == "fp32" else PEAK_BF16_MFMA_TFLOPS
         res[f"{name}_roofline"] = {"bound": "mfma", "achieved": tf, "peak": peak, "unit": "TFLOP/s", "frac": tf / peak}
@@ -204,7 +209,7 @@ def main():
                     help="fp32 = reference precision (the headline); bf16 = bf16 MFMA products, fp32 elsewhere")
     ap.add_argument("--no-decode", action="store_true")
     ap.add_argument("--no-side-streams", action="store_true", help="single-stream step (diagnostic)")
-    ap.add_argument("--decode-images", type=int, default=1024, help="images per GPU for the decode leg")
+    ap.add_argument("--decode-images", type=int, default=4096, help="images per GPU for the decode leg")
     ap.add_argument("--detail", action="store_true", help="print the per-shape kernel table to stderr")
     args = ap.parse_args()
     if os.environ.get("CAPDEC_HANG_DUMP"):  # debugging aid: dump every thread's stack after N seconds and exit

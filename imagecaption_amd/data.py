@@ -13,7 +13,6 @@
   contract of ref dataset.py:185-235 with features in place of the image tensor.
 """
 import json
-import os
 import re
 
 import numpy as np

@@ -24,7 +24,7 @@ import math
 
 import torch
 
-from . import _capi, engine, ops
+from . import engine, ops
 from ._capi import ACT_GELU, check, lib, ptr, stream
 
 START = 1

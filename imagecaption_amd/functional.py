@@ -6,7 +6,7 @@ These make the drop-in ``nn.Module`` surface differentiable, so the reference's 
 import torch
 
 from . import engine, ops
-from ._capi import ACT_GELU, ACT_NONE
+from ._capi import ACT_GELU
 
 
 def _flat2(x):

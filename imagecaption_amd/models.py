@@ -18,7 +18,7 @@ import torch
 import torch.nn as nn
 
 from . import engine
-from ._capi import ACT_GELU, ACT_NONE
+from ._capi import ACT_NONE
 from .engine import DropoutPlan
 from .functional import DecoderStackFn, EmbedFn, HeadFn, LayerNormFn, LinearFn, PEAddFn, ProjectionFn
 

@@ -9,7 +9,7 @@ import math
 import torch
 
 from . import _capi
-from ._capi import ACT_GELU, ACT_GELU_BWD, ACT_NONE, F32, check, lib, ptr, stream
+from ._capi import ACT_GELU_BWD, ACT_NONE, F32, check, lib, ptr, stream
 
 __all__ = ["compute_dtype", "gemm", "linear_fwd", "linear_dgrad", "linear_wgrad", "layernorm_fwd", "layernorm_bwd", "embed_fwd",
            "embed_bwd", "attn_fwd", "attn_bwd", "softmax_ce", "reduce_sum", "sumsq", "adamw", "clip_scale", "pe_add",

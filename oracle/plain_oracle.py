@@ -14,7 +14,6 @@ Arithmetic sites restated (torch/ = site-packages/torch):
 import math
 
 import torch
-import torch.nn.functional as F
 
 
 def layer_norm(x, w, b, eps=1e-5):

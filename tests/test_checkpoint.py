@@ -2,7 +2,6 @@
 
 CPU only: a synthetic 'reference' model = fake ViT (parameters only, registered first) + the oracle's
 decoder-path modules, trained one AdamW step, saved exactly as the reference saves."""
-import copy
 
 import pytest
 import torch

@@ -1,6 +1,5 @@
 """Edge cases of the drop-in module and trainer against the live CPU oracle (tiny config): degenerate and
 ragged shapes, all-PAD targets, strided inputs, and the error behaviour at the limits."""
-import numpy as np
 import pytest
 import torch
 

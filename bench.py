@@ -101,11 +101,6 @@ def decode_bench(model, cfg, dev, rank, world, dtype="fp32", images=4096, max_le
     for name, fn in (("beam3", lambda: dec.beam(feats, beam=3, max_len=max_len)),
                      ("beam5", lambda: dec.beam(feats, beam=5, max_len=max_len)),
                      ("greedy", lambda: dec.greedy(feats, max_len=max_len)),
-                     # the same loops replayed from a captured hipGraph (measured: no gain at >= 1024 images,
-                     # the loop is GPU-bound there; kept behind CAPDEC_BENCH_GRAPH=1)
-                     *((("beam3_graph", lambda: dec.beam(feats, beam=3, max_len=max_len, use_graph=True)),
-                        ("greedy_graph", lambda: dec.greedy(feats, max_len=max_len, use_graph=True)))
-                       if os.environ.get("CAPDEC_BENCH_GRAPH") == "1" else ()),
                      # the reference's own decode (train.py:289-412: temperature 0.7, top-5 draw, sentence rules)
                      ("sampler", lambda: dec.sample(feats, max_len=max_len + 1, seed=1))):
         fn()
@@ -123,7 +118,7 @@ def decode_bench(model, cfg, dev, rank, world, dtype="fp32", images=4096, max_le
             dist.all_reduce(t, op=dist.ReduceOp.MAX)
             dt = float(t.item())
         res[f"{name}_captions_per_sec"] = images * world / dt
-        W = {"beam3": 3, "beam5": 5, "beam3_graph": 3}.get(name, 1)
+        W = {"beam3": 3, "beam5": 5}.get(name, 1)
         tf = decode_flops_per_image(cfg, W, max_len) * images / dt / 1e12  # per GPU (dt is the slowest rank's)
         peak = PEAK_F32_MFMA_TFLOPS if dtype == "fp32" else PEAK_BF16_MFMA_TFLOPS
         res[f"{name}_roofline"] = {"bound": "mfma", "achieved": tf, "peak": peak, "unit": "TFLOP/s", "frac": tf / peak}

@@ -37,24 +37,26 @@ __global__ __launch_bounds__(256) void embed_fwd_kernel(const int64_t* __restric
 // in chunk order.  No float atomics: the result is bitwise reproducible.
 __device__ __forceinline__ int clamp_id(int64_t id, int V) { return (int)(id < 0 ? 0 : (id >= V ? V - 1 : id)); }
 
+// rank[m] = number of rows before m with the same id.  Block (tb, tm), tb <= tm, adds what the 256 rows of tile tb
+// contribute to the rows of tile tm (integer atomics: order-independent); the (tiles x tiles)/2 grid keeps every CU
+// busy, where one block per row tile walking all earlier tiles left the launch on a handful of CUs.
 __global__ __launch_bounds__(256) void embed_rank_kernel(const int64_t* __restrict__ ids, int* __restrict__ count,
                                                           int* __restrict__ rank, int BT, int V) {
     __shared__ int tile[256];
-    const int m = blockIdx.x * 256 + threadIdx.x;
+    const int tb = blockIdx.x, tm = blockIdx.y;
+    if (tb > tm) return;
+    const int m = tm * 256 + threadIdx.x;
     const int my = m < BT ? clamp_id(ids[m], V) : -1;
+    const int j = tb * 256 + threadIdx.x;
+    tile[threadIdx.x] = j < BT ? clamp_id(ids[j], V) : -2;
+    __syncthreads();
+    const int lim = tb < tm ? 256 : (int)threadIdx.x;  // only rows before m
     int r = 0;
-    for (int t = 0; t <= (int)blockIdx.x; ++t) {
-        const int j = t * 256 + threadIdx.x;
-        __syncthreads();
-        tile[threadIdx.x] = j < BT ? clamp_id(ids[j], V) : -2;
-        __syncthreads();
-        const int lim = t < (int)blockIdx.x ? 256 : (int)threadIdx.x;  // only rows before m
 #pragma unroll 8
-        for (int k = 0; k < 256; ++k) r += (k < lim && tile[k] == my) ? 1 : 0;
-    }
+    for (int k = 0; k < 256; ++k) r += (k < lim && tile[k] == my) ? 1 : 0;
     if (m < BT) {
-        rank[m] = r;
-        atomicAdd(&count[my], 1);  // integer atomics: order-independent result
+        if (r) atomicAdd(&rank[m], r);
+        if (tb == tm) atomicAdd(&count[my], 1);
     }
 }
 
@@ -200,34 +202,62 @@ extern "C" size_t capdec_embed_bwd_workspace_bytes(int B, int T, int d, int V) {
     return (embed_ws_ints(B * T, V) + (size_t)B * T * d) * sizeof(float);
 }
 
-extern "C" int capdec_embed_bwd(const int64_t* ids, const void* dout, void* dE, int B, int T, int d, int V, float drop_p,
-                                uint64_t drop_seed, void* workspace, size_t workspace_bytes, capdec_stream_t stream) {
-    CAPDEC_REQUIRE(ids && dout && dE, "capdec_embed_bwd: null pointer");
-    CAPDEC_REQUIRE(B > 0 && T > 0 && V > 0 && d > 0 && d % 4 == 0 && d <= 2048, "capdec_embed_bwd: bad shape");
-    CAPDEC_REQUIRE(aligned16(dout) && aligned16(dE) && aligned16(workspace), "capdec_embed_bwd: unaligned");
-    CAPDEC_REQUIRE((uint64_t)B * T * d < (1ull << 32), "capdec_embed_bwd: B*T*d exceeds 2^32");
-    const int BT = B * T;
+// The sort (count / offset / rank / order, the int head of the workspace) depends on the token ids only, so a
+// trainer can run capdec_embed_bwd_plan early -- off the critical path, e.g. beside the forward pass -- and only
+// capdec_embed_bwd_apply (partial sums + combine) at the end of backward.  capdec_embed_bwd = plan + apply.
+static int embed_check(const char* what, const int64_t* ids, int B, int T, int d, int V, const void* workspace,
+                       size_t workspace_bytes) {
+    CAPDEC_REQUIRE(ids, "%s: null ids", what);
+    CAPDEC_REQUIRE(B > 0 && T > 0 && V > 0 && d > 0 && d % 4 == 0 && d <= 2048, "%s: bad shape", what);
+    CAPDEC_REQUIRE((uint64_t)B * T * d < (1ull << 32), "%s: B*T*d exceeds 2^32", what);
+    CAPDEC_REQUIRE(aligned16(workspace), "%s: unaligned workspace", what);
     const size_t need = capdec_embed_bwd_workspace_bytes(B, T, d, V);
     if (!workspace || workspace_bytes < need) {
-        set_error("capdec_embed_bwd: needs %zu workspace bytes, got %zu", need, workspace_bytes);
+        set_error("%s: needs %zu workspace bytes, got %zu", what, need, workspace_bytes);
         return CAPDEC_ERR_WORKSPACE;
     }
+    return CAPDEC_OK;
+}
+
+extern "C" int capdec_embed_bwd_plan(const int64_t* ids, int B, int T, int d, int V, void* workspace,
+                                     size_t workspace_bytes, capdec_stream_t stream) {
+    if (int rc = embed_check("capdec_embed_bwd_plan", ids, B, T, d, V, workspace, workspace_bytes)) return rc;
+    const int BT = B * T;
     int* count = (int*)workspace;
     int* offset = count + V;
     int* rank = offset + V + 1;
     int* order = rank + BT;
-    float* part = (float*)workspace + embed_ws_ints(BT, V);
     hipStream_t st = (hipStream_t)stream;
-    if (hipMemsetAsync(count, 0, (size_t)V * sizeof(int), st) != hipSuccess) {
-        set_error("capdec_embed_bwd: memset failed");
+    // count [V], offset [V+1] and rank [BT] are contiguous: one memset zeroes the two accumulated arrays
+    if (hipMemsetAsync(count, 0, ((size_t)2 * V + 1 + BT) * sizeof(int), st) != hipSuccess) {
+        set_error("capdec_embed_bwd_plan: memset failed");
         return CAPDEC_ERR_LAUNCH;
     }
     const int nb = (BT + 255) / 256;
-    hipLaunchKernelGGL(embed_rank_kernel, dim3(nb), dim3(256), 0, st, ids, count, rank, BT, V);
+    hipLaunchKernelGGL(embed_rank_kernel, dim3(nb, nb), dim3(256), 0, st, ids, count, rank, BT, V);
     hipLaunchKernelGGL(embed_scan_kernel, dim3(1), dim3(1024), 0, st, (const int*)count, offset, V);
     hipLaunchKernelGGL(embed_order_kernel, dim3(nb), dim3(256), 0, st, ids, (const int*)offset, (const int*)rank, order, BT, V);
-    hipLaunchKernelGGL(embed_partial_kernel, dim3((BT + 127) / 128), dim3(256), 0, st, ids, (const int*)order,
-                       (const float*)dout, part, BT, d, V, make_dropout(drop_p, drop_seed));
-    hipLaunchKernelGGL(embed_combine_kernel, dim3(V), dim3(256), 0, st, (const int*)offset, (const float*)part, (float*)dE, d);
-    return check_launch("capdec_embed_bwd");
+    return check_launch("capdec_embed_bwd_plan");
+}
+
+extern "C" int capdec_embed_bwd_apply(const int64_t* ids, const void* dout, void* dE, int B, int T, int d, int V,
+                                      float drop_p, uint64_t drop_seed, void* workspace, size_t workspace_bytes,
+                                      capdec_stream_t stream) {
+    if (int rc = embed_check("capdec_embed_bwd_apply", ids, B, T, d, V, workspace, workspace_bytes)) return rc;
+    CAPDEC_REQUIRE(dout && dE && aligned16(dout) && aligned16(dE), "capdec_embed_bwd_apply: null or unaligned operand");
+    const int BT = B * T;
+    const int* offset = (const int*)workspace + V;
+    const int* order = offset + V + 1 + BT;
+    float* part = (float*)workspace + embed_ws_ints(BT, V);
+    hipStream_t st = (hipStream_t)stream;
+    hipLaunchKernelGGL(embed_partial_kernel, dim3((BT + 127) / 128), dim3(256), 0, st, ids, order, (const float*)dout, part,
+                       BT, d, V, make_dropout(drop_p, drop_seed));
+    hipLaunchKernelGGL(embed_combine_kernel, dim3(V), dim3(256), 0, st, offset, (const float*)part, (float*)dE, d);
+    return check_launch("capdec_embed_bwd_apply");
+}
+
+extern "C" int capdec_embed_bwd(const int64_t* ids, const void* dout, void* dE, int B, int T, int d, int V, float drop_p,
+                                uint64_t drop_seed, void* workspace, size_t workspace_bytes, capdec_stream_t stream) {
+    if (int rc = capdec_embed_bwd_plan(ids, B, T, d, V, workspace, workspace_bytes, stream)) return rc;
+    return capdec_embed_bwd_apply(ids, dout, dE, B, T, d, V, drop_p, drop_seed, workspace, workspace_bytes, stream);
 }

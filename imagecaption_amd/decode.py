@@ -46,7 +46,6 @@ class CaptionDecoder:
         self.d = model.embedding.weight.shape[1]
         self.V = model.embedding.weight.shape[0]
         self.dp = engine.DropoutPlan(0.0)
-        self._graphs = {}
 
     # ---- one decode step for R = N*W rows at position t ------------------------------------------
     def _step(self, tok, t, st):
@@ -100,39 +99,9 @@ class CaptionDecoder:
                   seq=[torch.zeros((R, Tmax), dtype=torch.int32, device=dev) for _ in range(2)])
         return st
 
-    # ---- hipGraph replay ---------------------------------------------------------------------------
-    # A whole greedy / beam decode (max_len steps x ~85 launches, every scalar argument a function of the
-    # step index only, nothing synchronising with the host) is one static launch sequence: captured once
-    # per (shape, width, length) through torch's capture of the current stream -- the C-ABI launches go to
-    # whatever stream torch hands out, so they are recorded like any other -- and replayed thereafter.
-    # At small row counts the eager loop is bound by the host's ~17 us per launch, the replay is not.
-    def _replay(self, kind, features, W, max_len, return_gap):
-        key = (kind, tuple(features.shape), features.device, W, max_len, self.dtype, return_gap)
-        entry = self._graphs.get(key)
-        if entry is None:
-            static_in = features.clone()
-            run = (lambda: self.greedy(static_in, max_len, return_gap)) if kind == "greedy" else \
-                (lambda: self.beam(static_in, W, max_len, return_gap))
-            warm = torch.cuda.Stream(device=features.device)  # eager pass first: workspaces, lazy module loads
-            warm.wait_stream(torch.cuda.current_stream())
-            with torch.cuda.stream(warm):
-                run()
-            torch.cuda.current_stream().wait_stream(warm)
-            torch.cuda.synchronize()
-            graph = torch.cuda.CUDAGraph()
-            with torch.cuda.graph(graph):
-                out = run()
-            entry = self._graphs[key] = (graph, static_in, out)
-        graph, static_in, out = entry
-        static_in.copy_(features)
-        graph.replay()
-        return tuple(o.clone() for o in out) if isinstance(out, tuple) else out.clone()
-
     @torch.no_grad()
-    def greedy(self, features, max_len=20, return_gap=False, use_graph=False):
+    def greedy(self, features, max_len=20, return_gap=False):
         """ids [N, max_len] int64 (without START; PAD after END)."""
-        if use_graph:
-            return self._replay("greedy", features, 1, max_len, return_gap)
         st = self._prepare(features, 1, max_len)
         R, dev = st["R"], features.device
         tok = torch.full((R,), START, dtype=torch.int64, device=dev)
@@ -148,10 +117,8 @@ class CaptionDecoder:
         return (ids, gap) if return_gap else ids
 
     @torch.no_grad()
-    def beam(self, features, beam=3, max_len=20, return_gap=False, use_graph=False):
+    def beam(self, features, beam=3, max_len=20, return_gap=False):
         """ids [N, beam, max_len] int64 (best first), scores [N, beam] fp32 (sum of log-probs)."""
-        if use_graph:
-            return self._replay("beam", features, beam, max_len, return_gap)
         st = self._prepare(features, beam, max_len)
         N, R, dev = st["N"], st["R"], features.device
         tok = torch.full((R,), START, dtype=torch.int64, device=dev)

@@ -5,6 +5,8 @@ may be row-strided views (``stride(1) == 1``), e.g. the q / k / v slices of a pa
 """
 import ctypes as C
 import math
+import os
+import sys
 
 import torch
 
@@ -37,26 +39,56 @@ class compute_dtype:
         COMPUTE_DTYPE = self.prev
 
 
-# ---- streams ------------------------------------------------------------------------------------
-# HIP multiplexes all streams of one priority over 4 hardware queues by reference count, so two
-# normal-priority streams may share a queue (observed: once RCCL had created its streams the trainer's
-# side lane landed on the caller's queue and every overlap was gone).  High-priority streams draw from
-# their own queue pool.  The trainer therefore runs its step on TWO high-priority streams of its own --
-# slot 0 the critical path, slot 1 the weight-gradient lane -- which cannot share a queue with the
-# caller's stream, the DP reducer's stream or RCCL's (all normal priority).  Exactly two, shared by
-# every trainer of the process: on this ROCm stack the 4th high-priority stream of a process deadlocks
-# (tools/hp_stream_probe.py).
-_HP_STREAMS = {}
+# ---- the weight-gradient lane -----------------------------------------------------------------------
+# HIP multiplexes all streams of one priority over 4 hardware queues by reference count, so a second stream may
+# land on the SAME queue as the caller's stream and then runs strictly in order with it (observed once RCCL had
+# created its streams: sum of kernel durations = GPU busy time, the overlap was gone).  Which queue a stream gets
+# cannot be asked, but it can be measured: the lane is chosen at construction by racing a short MFMA probe on the
+# caller's stream against one on each candidate and keeping the first candidate that really runs beside it.
+# (High-priority streams would separate the queues by construction, but on this ROCm stack they deadlock -- the
+# 4th one created in a process, or any of them after a hipGraph launch: tools/hp_stream_probe.py.)
+_LANES = {}
 
 
-def hp_stream(device, slot):
-    key = (torch.device(device).index if torch.device(device).index is not None else torch.cuda.current_device(), slot)
-    if key not in _HP_STREAMS:
-        for s in range(slot + 1):  # create in slot order so slot numbers match creation order
-            k = (key[0], s)
-            if k not in _HP_STREAMS:
-                _HP_STREAMS[k] = torch.cuda.Stream(device=key[0], priority=-1)
-    return _HP_STREAMS[key]
+def _runs_beside_current(cand, device):
+    import ctypes as C
+    import time
+    l = lib()
+    out = torch.zeros(16, dtype=torch.float32, device=device)
+
+    def race(both):
+        torch.cuda.synchronize(device)
+        t0 = time.perf_counter()
+        check(l.capdec_probe_mfma(F32, 8, 6000, ptr(out), C.POINTER(C.c_double)(), stream()), "capdec_probe_mfma")
+        if both:
+            with torch.cuda.stream(cand):
+                check(l.capdec_probe_mfma(F32, 8, 6000, ptr(out), C.POINTER(C.c_double)(), stream()), "capdec_probe_mfma")
+        torch.cuda.synchronize(device)
+        return time.perf_counter() - t0
+
+    race(True)  # warm-up (module load, clocks)
+    single = min(race(False) for _ in range(2))
+    pair = min(race(True) for _ in range(2))
+    return pair < 1.5 * single
+
+
+def lane_stream(device):
+    """A normal-priority stream verified to execute concurrently with the current stream (cached per device and
+    current stream)."""
+    device = torch.device(device)
+    cur = torch.cuda.current_stream(device)
+    key = (device.index if device.index is not None else torch.cuda.current_device(), cur.cuda_stream)
+    if key not in _LANES:
+        cand = None
+        for attempt in range(8):
+            cand = torch.cuda.Stream(device=device)
+            if _runs_beside_current(cand, device):
+                break
+        if os.environ.get("CAPDEC_DEBUG_LANE"):
+            print(f"[capdec] lane stream: candidate #{attempt} {'runs beside' if attempt < 7 else 'last tried for'} "
+                  f"stream {cur.cuda_stream:#x}", file=sys.stderr, flush=True)
+        _LANES[key] = cand  # the last candidate if none qualified: correct, merely without overlap
+    return _LANES[key]
 
 
 class SideStream:
@@ -67,8 +99,7 @@ class SideStream:
     so the caching allocator never sees a cross-stream free."""
 
     def __init__(self, device):
-        self.main = hp_stream(device, 0)
-        self.stream = hp_stream(device, 1)
+        self.stream = lane_stream(device)
         self.streams = (self.stream,)
         self.keep = []       # tensors the lane still reads; released at join()
         self.pending = False
@@ -93,26 +124,6 @@ class SideStream:
             torch.cuda.current_stream().wait_stream(self.stream)
             self.keep.clear()
             self.pending = False
-
-
-class on_stream:
-    """Run a block on ``stream`` between the caller's stream's past and future: the stream first waits for
-    everything the caller has enqueued, and the caller's stream waits for the block at exit."""
-
-    def __init__(self, stream):
-        self.stream = stream
-
-    def __enter__(self):
-        self.outer = torch.cuda.current_stream()
-        self.stream.wait_stream(self.outer)
-        self.ctx = torch.cuda.stream(self.stream)
-        self.ctx.__enter__()
-        return self
-
-    def __exit__(self, *exc):
-        self.ctx.__exit__(*exc)
-        self.outer.wait_stream(self.stream)
-        return False
 
 
 _WS_TAG = "main"
@@ -261,7 +272,21 @@ def embed_fwd(ids, E, pe, t0=0, drop_p=0.0, seed=0):
     return out
 
 
-def embed_bwd(ids, dout, V, drop_p=0.0, seed=0, dE=None):
+def embed_bwd_workspace(B, T, d, V, device):
+    """A private workspace for the plan / apply pair (the shared per-device workspace is reused by every GEMM)."""
+    return torch.empty(lib().capdec_embed_bwd_workspace_bytes(B, T, d, V), dtype=torch.uint8, device=device)
+
+
+def embed_bwd_plan(ids, d, V, ws):
+    """The ids-only half of embed_bwd (stable sort of the rows by token) into ``ws``; see capdec_embed_bwd_plan."""
+    ids = _req(ids, "embed_bwd_plan.ids", torch.int64).contiguous()
+    B, T = ids.shape
+    check(lib().capdec_embed_bwd_plan(ptr(ids), B, T, d, V, ptr(ws), ws.numel(), stream()), "capdec_embed_bwd_plan")
+
+
+def embed_bwd(ids, dout, V, drop_p=0.0, seed=0, dE=None, planned_ws=None):
+    """dE[v] = sum of the (dropout-masked) rows of dout whose id is v.  ``planned_ws``: a workspace already filled by
+    ``embed_bwd_plan`` for these ids (then only the summation runs here)."""
     ids = ids.contiguous()
     B, T = ids.shape
     d = dout.shape[-1]
@@ -269,6 +294,10 @@ def embed_bwd(ids, dout, V, drop_p=0.0, seed=0, dE=None):
     if dE is None:
         dE = torch.empty((V, d), dtype=torch.float32, device=dout.device)
     l = lib()
+    if planned_ws is not None:
+        check(l.capdec_embed_bwd_apply(ptr(ids), ptr(_req(dout, "embed_bwd.dout")), ptr(dE), B, T, d, V, float(drop_p),
+                                       int(seed), ptr(planned_ws), planned_ws.numel(), stream()), "capdec_embed_bwd_apply")
+        return dE
     ws = _capi.workspace(l.capdec_embed_bwd_workspace_bytes(B, T, d, V), dout.device)
     check(l.capdec_embed_bwd(ptr(ids), ptr(_req(dout, "embed_bwd.dout")), ptr(dE), B, T, d, V, float(drop_p), int(seed),
                              ptr(ws), ws.numel(), stream()), "capdec_embed_bwd")

@@ -69,22 +69,13 @@ class CaptionTrainer:
 
     # ---- one iteration of ref train.py:24-61 ---------------------------------------------------------
     def forward_backward(self, features, captions, train=True, keep_logits=False):
-        if self.side is None:
-            with ops.compute_dtype(self.dtype):
-                return self._forward_backward(features, captions, train, keep_logits)
         prev, ops.SIDE = ops.SIDE, self.side
         try:
-            # critical path on the trainer's own high-priority stream (see ops.hp_stream), lane beside it
-            with ops.on_stream(self.side.main) as scope, ops.compute_dtype(self.dtype):
-                try:
-                    loss, keep = self._forward_backward(features, captions, train, keep_logits)
-                finally:
-                    self.side.join()
-            for t in (loss, keep):
-                if t is not None:
-                    t.record_stream(scope.outer)  # allocated on the trainer's stream, consumed on the caller's
-            return loss, keep
+            with ops.compute_dtype(self.dtype):
+                return self._forward_backward(features, captions, train, keep_logits)
         finally:
+            if self.side is not None:
+                self.side.join()
             ops.SIDE = prev
 
     def _forward_backward(self, features, captions, train, keep_logits):
@@ -133,12 +124,6 @@ class CaptionTrainer:
 
     def optimizer_step(self):
         self.step_count += 1
-        if self.side is None:
-            return self._optimizer_step()
-        with ops.on_stream(self.side.main):
-            self._optimizer_step()
-
-    def _optimizer_step(self):
         ops.sumsq(self.flat_g, out=self.gnorm_sq)
         ops.adamw(self.flat_p, self.flat_g, self.flat_m, self.flat_v, self.step_count, self.lr, self.betas, self.eps,
                   self.wd, gnorm_sq=self.gnorm_sq, max_norm=self.max_norm)

@@ -102,6 +102,12 @@ int capdec_embed_fwd(const int64_t* ids, const void* E, const void* pe, void* ou
 size_t capdec_embed_bwd_workspace_bytes(int B, int T, int d, int V);
 int capdec_embed_bwd(const int64_t* ids, const void* dout, void* dE, int B, int T, int d, int V, float drop_p,
                      uint64_t drop_seed, void* workspace, size_t workspace_bytes, capdec_stream_t stream);
+/* capdec_embed_bwd = plan + apply.  The plan (the stable sort of the rows by token id, kept in the int head of the
+ * workspace) depends on ids only: run it early, off the critical path; apply needs the SAME workspace untouched. */
+int capdec_embed_bwd_plan(const int64_t* ids, int B, int T, int d, int V, void* workspace, size_t workspace_bytes,
+                          capdec_stream_t stream);
+int capdec_embed_bwd_apply(const int64_t* ids, const void* dout, void* dE, int B, int T, int d, int V, float drop_p,
+                           uint64_t drop_seed, void* workspace, size_t workspace_bytes, capdec_stream_t stream);
 
 /* ---- fused attention (scores, softmax, context) --------------------------------------------------
  * o[b,tq,h,:] = sum_tk dropout(softmax_tk(scale * q[b,tq,h,:].k[b,tk,h,:] + causal)) v[b,tk,h,:]

@@ -204,18 +204,3 @@ def test_sampler_draw_frequencies_follow_the_top5_distribution():
     assert int(counts.sum()) == n  # never outside the top-5
     chi2 = float((((counts - n * probs) ** 2) / (n * probs)).sum())
     assert chi2 < 23.5, (chi2, counts.tolist(), (n * probs).tolist())
-
-
-def test_graph_replay_equals_eager_decode():
-    """greedy / beam through a captured hipGraph: identical ids and scores, also on a second batch of the same shape."""
-    from imagecaption_amd.decode import CaptionDecoder
-    ref, model = _sampler_models()
-    dec = CaptionDecoder(model)
-    g = torch.Generator().manual_seed(21)
-    for trial in range(2):
-        feats = torch.randn(6, 5, TINY["feature_dim"], generator=g).to(DEV)
-        assert torch.equal(dec.greedy(feats, max_len=12, use_graph=True), dec.greedy(feats, max_len=12))
-        ids_g, sc_g = dec.beam(feats, beam=3, max_len=12, use_graph=True)
-        ids_e, sc_e = dec.beam(feats, beam=3, max_len=12)
-        assert torch.equal(ids_g, ids_e) and torch.equal(sc_g, sc_e)
-    assert len(dec._graphs) == 2

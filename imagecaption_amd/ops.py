@@ -50,6 +50,11 @@ class compute_dtype:
 _LANES = {}
 
 
+def _runs_beside(base, cand, device):
+    with torch.cuda.stream(base):
+        return _runs_beside_current(cand, device)
+
+
 def _runs_beside_current(cand, device):
     import ctypes as C
     import time
@@ -72,20 +77,23 @@ def _runs_beside_current(cand, device):
     return pair < 1.5 * single
 
 
-def lane_stream(device):
-    """A normal-priority stream verified to execute concurrently with the current stream (cached per device and
-    current stream)."""
+def lane_stream(device, slot=0):
+    """A normal-priority stream verified to execute concurrently with the current stream and with the lanes of
+    lower slot numbers (cached per device, current stream and slot).  Slot 0: weight gradients; slot 1: the DP
+    reducer's collectives."""
     device = torch.device(device)
     cur = torch.cuda.current_stream(device)
-    key = (device.index if device.index is not None else torch.cuda.current_device(), cur.cuda_stream)
+    index = device.index if device.index is not None else torch.cuda.current_device()
+    key = (index, cur.cuda_stream, slot)
     if key not in _LANES:
+        others = [lane_stream(device, s) for s in range(slot)]
         cand = None
         for attempt in range(8):
             cand = torch.cuda.Stream(device=device)
-            if _runs_beside_current(cand, device):
+            if _runs_beside_current(cand, device) and all(_runs_beside(o, cand, device) for o in others):
                 break
         if os.environ.get("CAPDEC_DEBUG_LANE"):
-            print(f"[capdec] lane stream: candidate #{attempt} {'runs beside' if attempt < 7 else 'last tried for'} "
+            print(f"[capdec] lane stream (slot {slot}): candidate #{attempt} {'runs beside' if attempt < 7 else 'last tried for'} "
                   f"stream {cur.cuda_stream:#x}", file=sys.stderr, flush=True)
         _LANES[key] = cand  # the last candidate if none qualified: correct, merely without overlap
     return _LANES[key]

@@ -62,8 +62,12 @@ class BucketReducer:
         # device collectives deadlock on this stack while the GPU is busy (reproduced with plain torch,
         # tools/gloo_probe2.py), so that combination stages the buckets through host memory in finish().
         self.serial = self.active and flat_g.is_cuda and dist.get_backend(process_group) == "gloo"
-        self.side = torch.cuda.Stream(device=flat_g.device) \
-            if (overlap and self.active and flat_g.is_cuda and not self.serial) else None
+        # the collectives' stream is picked by measurement like the weight-gradient lane (ops.lane_stream): it must
+        # not share a hardware queue with the compute stream, or RCCL's kernels run in line with backward
+        self.side = None
+        if overlap and self.active and flat_g.is_cuda and not self.serial:
+            from . import ops
+            self.side = ops.lane_stream(flat_g.device, slot=1)
         self.works, self.deferred = [], []
 
     def reduce(self, idx, after=()):
@@ -83,7 +87,9 @@ class BucketReducer:
             for st in after:
                 self.side.wait_stream(st)
             with torch.cuda.stream(self.side):
-                self.works.append(dist.all_reduce(buf, op=dist.ReduceOp.SUM, group=self.pg, async_op=True))
+                # async_op=False: current ProcessGroupNCCL launches a synchronous collective on the CURRENT stream
+                # (here: the measured side stream) instead of its own pool stream; the host does not block
+                dist.all_reduce(buf, op=dist.ReduceOp.SUM, group=self.pg, async_op=False)
         else:
             for st in after:
                 torch.cuda.current_stream().wait_stream(st)

@@ -2,8 +2,7 @@
 
 This is the host-side "graph" of the build.  It is a fixed sequence of C-ABI launches per block
 (no tracing compiler): the same functions serve the autograd wrappers of ``functional.py`` (drop-in
-nn.Module path) and the allocation-light trainer / decoder of ``trainer.py`` / ``decode.py`` (which
-may capture them in a hipGraph).
+nn.Module path) and the allocation-light trainer / decoder of ``trainer.py`` / ``decode.py``.
 
 The arithmetic mirrors, block for block, what the reference executes through torch.nn:
 * decoder layer, post-norm:       torch/nn/modules/transformer.py:1143-1199 (as built at ref models.py:53-65)

@@ -10,6 +10,9 @@ but as a fixed launch plan over flat HBM-resident blocks instead of autograd ove
 * weight-gradient GEMMs write straight into the flat gradient block (no ``.grad`` accumulation
   pass, no ``zero_grad``); clip + AdamW is one streaming kernel reading the norm from device memory
   (the reference's ``loss.item()`` / clip host syncs are gone: nothing here synchronises);
+* weight-gradient GEMMs are enqueued on a second stream (``ops.SideStream``, a lane verified by
+  measurement to run beside the caller's stream): they depend on nothing later in backward and fill
+  the matrix pipes while the critical path runs its latency-bound kernels;
 * data parallel: the block is cut into buckets in backward order (head, layer L-1 .. 0,
   projection + embedding); each bucket's RCCL all-reduce(sum) is issued on a side stream as soon as
   its last gradient kernel is enqueued, overlapping the rest of backward.  The loss gradient is
@@ -32,7 +35,9 @@ class CaptionTrainer:
         self.lr, self.betas, self.eps, self.wd = lr, betas, eps, weight_decay
         self.max_norm, self.smooth, self.p, self.seed = max_norm, smooth_factor, dropout, seed
         self.pg = process_group
-        self.dtype = dtype  # "fp32" (reference precision) or "bf16" (bf16 MFMA products, fp32 everything else)
+        # "fp32" (exact fp32 MFMA, the reference's precision), "f32x3" (split-bf16 products, fp32-level accuracy)
+        # or "bf16" (bf16 MFMA products, fp32 everything else)
+        self.dtype = dtype
         self.world = dist.get_world_size(process_group) if (dist.is_available() and dist.is_initialized()) else 1
         self.step_count = 0
         dec = model.transformer_decoder

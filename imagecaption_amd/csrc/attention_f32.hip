@@ -129,33 +129,36 @@ __device__ __forceinline__ void spread_rows(float* line, float val, float* outv,
 }
 
 template <int DH>
-__global__ __launch_bounds__(64) void attn_fwd_kernel(AttnParams p) {
+__global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(DH <= 64 ? 3 : 1))) void attn_fwd_kernel(AttnParams p) {
     constexpr int LD = DH + 4;
-    __shared__ __attribute__((aligned(16))) float Ks[32 * LD];
-    __shared__ __attribute__((aligned(16))) float Vs[32 * LD];
+    // ONE tile image, holding K while the scores are computed and V while they are applied: half the
+    // LDS and (with a single staging register set that always carries the next tile needed) ~100
+    // fewer registers than separate K and V images, which is what lets a third wave live on a SIMD.
+    __shared__ __attribute__((aligned(16))) float Ts[32 * LD];
     __shared__ __attribute__((aligned(16))) float line[32];
     const int lane = threadIdx.x, l31 = lane & 31, half = lane >> 5;
     const int nqt = (p.Tq + 31) / 32;
-    const int qt = blockIdx.x % nqt, bh = blockIdx.x / nqt;
+    // causal: the tiles of one (b, h) differ in length (query tile i walks i + 1 key tiles), so the
+    // longest ones are dispatched first and the short ones fill the tail of the launch
+    const int nbh = p.B * p.H;
+    const int qt = p.causal ? nqt - 1 - (int)blockIdx.x / nbh : (int)blockIdx.x % nqt;
+    const int bh = p.causal ? (int)blockIdx.x % nbh : (int)blockIdx.x / nqt;
     const int b = bh / p.H, h = bh % p.H;
     const int q0 = qt * 32, off = p.Tk - p.Tq;
     const float* qg = p.q + (size_t)b * p.Tq * p.ldq + h * DH;
     const float* kg = p.k + (size_t)b * p.Tk * p.ldk + h * DH;
     const float* vg = p.v + (size_t)b * p.Tk * p.ldv + h * DH;
 
-    float4 qf[DH / 8], kr[DH / 8], vr[DH / 8];
+    float4 qf[DH / 8], tr[DH / 8];
     const int query = q0 + l31;
     int kmax = p.Tk;
     if (p.causal) kmax = min(p.Tk, q0 + 31 + off + 1);
     const int nkt = kmax > 0 ? (kmax + 31) / 32 : 0;
     tile_gload<DH>(qf, qg, p.ldq, q0, p.Tq, lane);
-    if (nkt > 0) {
-        tile_gload<DH>(kr, kg, p.ldk, 0, p.Tk, lane);
-        tile_gload<DH>(vr, vg, p.ldv, 0, p.Tk, lane);
-    }
-    tile_lstore<DH>(Ks, qf, p.scale, lane);
+    if (nkt > 0) tile_gload<DH>(tr, kg, p.ldk, 0, p.Tk, lane);
+    tile_lstore<DH>(Ts, qf, p.scale, lane);
     __syncthreads();
-    lds_frag<DH>(qf, Ks, l31, half);
+    lds_frag<DH>(qf, Ts, l31, half);
     f32x16 oacc[DH / 32];
 #pragma unroll
     for (int dt = 0; dt < DH / 32; ++dt)
@@ -165,14 +168,10 @@ __global__ __launch_bounds__(64) void attn_fwd_kernel(AttnParams p) {
     for (int kt = 0; kt < nkt; ++kt) {
         const int k0 = kt * 32;
         __syncthreads();
-        tile_lstore<DH>(Ks, kr, 1.f, lane);
-        tile_lstore<DH>(Vs, vr, 1.f, lane);
+        tile_lstore<DH>(Ts, tr, 1.f, lane);  // K tile
         __syncthreads();
-        if (kt + 1 < nkt) {  // next tile's loads fly while this one is multiplied
-            tile_gload<DH>(kr, kg, p.ldk, k0 + 32, p.Tk, lane);
-            tile_gload<DH>(vr, vg, p.ldv, k0 + 32, p.Tk, lane);
-        }
-        f32x16 s = mma_lds_reg<DH>(Ks, qf, l31, half);
+        tile_gload<DH>(tr, vg, p.ldv, k0, p.Tk, lane);  // V tile flies under the score MFMAs
+        f32x16 s = mma_lds_reg<DH>(Ts, qf, l31, half);
         float mloc = -INFINITY;
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
@@ -200,13 +199,21 @@ __global__ __launch_bounds__(64) void attn_fwd_kernel(AttnParams p) {
 #pragma unroll
             for (int r = 0; r < 16; ++r) pr[r] = p.drop.apply(pr[r], base + (uint32_t)row_of(r, half));
         }
-        float arow[16];
-        spread_rows(line, alpha, arow, lane, half);
+        __syncthreads();  // every lane is done reading K
+        if (lane < 32) line[lane] = alpha;
+        tile_lstore<DH>(Ts, tr, 1.f, lane);  // V tile
+        __syncthreads();
+        if (kt + 1 < nkt) tile_gload<DH>(tr, kg, p.ldk, k0 + 32, p.Tk, lane);  // next K under the P V MFMAs
 #pragma unroll
-        for (int dt = 0; dt < DH / 32; ++dt)
+        for (int g = 0; g < 4; ++g) {
+            const float4 t = *reinterpret_cast<const float4*>(&line[8 * g + 4 * half]);
 #pragma unroll
-            for (int r = 0; r < 16; ++r) oacc[dt][r] *= arow[r];
-        mma_acc_lds<DH>(oacc, pr, Vs, l31, half);
+            for (int dt = 0; dt < DH / 32; ++dt) {
+                oacc[dt][4 * g + 0] *= t.x; oacc[dt][4 * g + 1] *= t.y;
+                oacc[dt][4 * g + 2] *= t.z; oacc[dt][4 * g + 3] *= t.w;
+            }
+        }
+        mma_acc_lds<DH>(oacc, pr, Ts, l31, half);
     }
     const float inv = l_run > 0.f ? 1.f / l_run : 0.f;
     float irow[16];
@@ -226,13 +233,17 @@ __global__ __launch_bounds__(64) void attn_fwd_kernel(AttnParams p) {
 
 // dQ (and delta = rowsum(dO * O)); wave owns 32 queries.
 template <int DH>
-__global__ __launch_bounds__(64) void attn_bwd_dq_kernel(AttnParams p) {
+__global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2))) void attn_bwd_dq_kernel(AttnParams p) {
     constexpr int LD = DH + 4;
     __shared__ __attribute__((aligned(16))) float Ks[32 * LD];
     __shared__ __attribute__((aligned(16))) float Vs[32 * LD];
     const int lane = threadIdx.x, l31 = lane & 31, half = lane >> 5;
     const int nqt = (p.Tq + 31) / 32;
-    const int qt = blockIdx.x % nqt, bh = blockIdx.x / nqt;
+    // causal: the tiles of one (b, h) differ in length (query tile i walks i + 1 key tiles), so the
+    // longest ones are dispatched first and the short ones fill the tail of the launch
+    const int nbh = p.B * p.H;
+    const int qt = p.causal ? nqt - 1 - (int)blockIdx.x / nbh : (int)blockIdx.x % nqt;
+    const int bh = p.causal ? (int)blockIdx.x % nbh : (int)blockIdx.x / nqt;
     const int b = bh / p.H, h = bh % p.H;
     const int q0 = qt * 32, off = p.Tk - p.Tq;
     const int query = q0 + l31;
@@ -314,8 +325,11 @@ __global__ __launch_bounds__(64) void attn_bwd_dq_kernel(AttnParams p) {
 }
 
 // dK, dV; wave owns 32 keys.  Must run after attn_bwd_dq_kernel (reads delta).
+// The next query tile's Q / dO rows are NOT prefetched into registers here: the 64 registers that
+// costs take away the second wave per SIMD at dh = 64, and the second resident wave hides the loads
+// better than the prefetch did (measured at every shape: C2 52 -> 38 us, C1 and C3 3-6 % faster).
 template <int DH>
-__global__ __launch_bounds__(64) void attn_bwd_dkv_kernel(AttnParams p) {
+__global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2))) void attn_bwd_dkv_kernel(AttnParams p) {
     constexpr int LD = DH + 4;
     __shared__ __attribute__((aligned(16))) float Qs[32 * LD];
     __shared__ __attribute__((aligned(16))) float dOs[32 * LD];
@@ -323,7 +337,9 @@ __global__ __launch_bounds__(64) void attn_bwd_dkv_kernel(AttnParams p) {
     __shared__ __attribute__((aligned(16))) float del_s[32];
     const int lane = threadIdx.x, l31 = lane & 31, half = lane >> 5;
     const int nkt = (p.Tk + 31) / 32;
-    const int kt = blockIdx.x % nkt, bh = blockIdx.x / nkt;
+    const int nbh = p.B * p.H;  // causal: key tile 0 meets every query tile, the last one few -> longest first
+    const int kt = p.causal ? (int)blockIdx.x / nbh : (int)blockIdx.x % nkt;
+    const int bh = p.causal ? (int)blockIdx.x % nbh : (int)blockIdx.x / nkt;
     const int b = bh / p.H, h = bh % p.H;
     const int k0 = kt * 32, off = p.Tk - p.Tq;
     const int key = k0 + l31;
@@ -353,12 +369,10 @@ __global__ __launch_bounds__(64) void attn_bwd_dkv_kernel(AttnParams p) {
         qstart = qmin > 0 ? (qmin / 32) : 0;
     }
     const int nqt = (p.Tq + 31) / 32;
-    if (qstart < nqt) {
-        tile_gload<DH>(qr, qg, p.ldq, qstart * 32, p.Tq, lane);
-        tile_gload<DH>(dr, dog, p.lddo, qstart * 32, p.Tq, lane);
-    }
     for (int qt = qstart; qt < nqt; ++qt) {
         const int q0 = qt * 32;
+        tile_gload<DH>(qr, qg, p.ldq, q0, p.Tq, lane);
+        tile_gload<DH>(dr, dog, p.lddo, q0, p.Tq, lane);
         __syncthreads();
         tile_lstore<DH>(Qs, qr, p.scale, lane);
         tile_lstore<DH>(dOs, dr, 1.f, lane);
@@ -368,10 +382,6 @@ __global__ __launch_bounds__(64) void attn_bwd_dkv_kernel(AttnParams p) {
             del_s[lane] = qq < p.Tq ? p.delta[(size_t)bh * p.Tq + qq] : 0.f;
         }
         __syncthreads();
-        if (qt + 1 < nqt) {
-            tile_gload<DH>(qr, qg, p.ldq, q0 + 32, p.Tq, lane);
-            tile_gload<DH>(dr, dog, p.lddo, q0 + 32, p.Tq, lane);
-        }
         f32x16 s = mma_lds_reg<DH>(Qs, kf, l31, half);    // S[query][key]
         f32x16 dp = mma_lds_reg<DH>(dOs, vf, l31, half);  // dP[query][key]
         float pd[16], ds[16];

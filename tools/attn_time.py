@@ -20,4 +20,4 @@ for name, B, H, T, S, d, causal in (("c2 cross", 256, 8, 20, 49, 512, False), ("
     tf = t(lambda: ops.attn_fwd(q, kv[:, :d], kv[:, d:], B, H, T, S, causal, 0.1, 7))
     tb = t(lambda: ops.attn_bwd(q, kv[:, :d], kv[:, d:], o, do, lse, B, H, T, S, causal, 0.1, 7))
     fb = 4.0 * B * d * (2 * T + 2 * S); bb = 4.0 * B * d * (4 * T + 4 * S)
-    print(f"waves/CU {os.environ.get('CAPDEC_ATTN_WAVES_PER_CU', 'default'):>7s} {name:9s} fwd {tf:7.1f} us {fb/tf/1e6:6.2f} TB/s | bwd {tb:7.1f} us {bb/tb/1e6:6.2f} TB/s", flush=True)
+    print(f"pf {os.environ.get('CAPDEC_ATTN_PF', 'auto'):>4s} {name:9s} fwd {tf:7.1f} us {fb/tf/1e6:6.2f} TB/s | bwd {tb:7.1f} us {bb/tb/1e6:6.2f} TB/s", flush=True)

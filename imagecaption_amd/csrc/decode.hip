@@ -142,7 +142,12 @@ __global__ __launch_bounds__(256) void greedy_select_kernel(const float* __restr
 }
 
 // one block per image: top-W of {score[w] + log_softmax(logits[w])[v]} over W*V candidates.
+// STAGE: each beam's logits row is read from memory ONCE (float4) into an LDS row buffer, and the
+// sum-exp and candidate passes run on that copy (the unstaged kernel reads the row three times);
+// both variants assign elements to threads identically, so their results are bit-identical.
 constexpr int MAXW = 8;
+// LW: length of the per-thread candidate list (>= W + 1); the insertion cost is what bounds this kernel
+template <bool STAGE, int LW>
 __global__ __launch_bounds__(256) void beam_select_kernel(const float* __restrict__ logits, int ldl,
                                                            const float* __restrict__ score_in, float* __restrict__ score_out,
                                                            const int* __restrict__ fin_in, int* __restrict__ fin_out,
@@ -150,18 +155,54 @@ __global__ __launch_bounds__(256) void beam_select_kernel(const float* __restric
                                                            const int* __restrict__ seq_in, int* __restrict__ seq_out,
                                                            int64_t* __restrict__ next_tok, float* __restrict__ gap, int W,
                                                            int V, int Tmax, int t) {
+    extern __shared__ __attribute__((aligned(16))) float rowbuf[];  // STAGE: V floats
     __shared__ Cand sh[4];
     __shared__ float red[4];
-    __shared__ float row_max[MAXW], row_logsum[MAXW], row_score[MAXW];
     __shared__ int row_fin[MAXW];
     __shared__ Cand picked[MAXW + 1];
     const int n = blockIdx.x, tid = threadIdx.x;
     const float NEG = -1.0e30f;
-    // 1. per-beam log-sum-exp (torch's log_softmax order: max, sum exp(z - max), log)
+    // per-thread top-LW over its strided share of the W*V candidates; the list length is a
+    // compile-time constant so it stays in registers
+    Cand loc[LW];
+#pragma unroll
+    for (int k = 0; k < LW; ++k) loc[k] = Cand{-INFINITY, 0x7fffffff};
+    auto offer = [&](float sc, int f) {
+        const Cand c{sc, f};
+        if (better(c, loc[LW - 1])) {
+            loc[LW - 1] = c;
+#pragma unroll
+            for (int k = LW - 1; k > 0; --k)
+                if (better(loc[k], loc[k - 1])) {
+                    const Cand tmp = loc[k]; loc[k] = loc[k - 1]; loc[k - 1] = tmp;
+                }
+        }
+    };
     for (int w = 0; w < W; ++w) {
-        const float* z = logits + (size_t)(n * W + w) * ldl;
+        const int row = n * W + w;
+        const float rscore = score_in[row];
+        const int rfin = fin_in[row];  // block-uniform
+        if (tid == 0) row_fin[w] = rfin;
+        if (rfin) {  // a finished beam only continues with PAD, at its own score
+            for (int v = tid; v < V; v += 256) offer(rscore + (v == TOK_PAD ? 0.f : NEG), w * V + v);
+            continue;
+        }
+        // log-sum-exp in torch's log_softmax order: max, sum exp(z - max), log
+        const float* z = logits + (size_t)row * ldl;
         float mx = -INFINITY;
-        for (int v = tid; v < V; v += 256) mx = fmaxf(mx, z[v]);
+        if (STAGE) {
+            __syncthreads();  // the previous row's readers are done with rowbuf
+            const float4* z4 = reinterpret_cast<const float4*>(z);
+            float4* b4 = reinterpret_cast<float4*>(rowbuf);
+            for (int i = tid; i < (V >> 2); i += 256) {
+                const float4 x = z4[i];
+                b4[i] = x;
+                mx = fmaxf(fmaxf(mx, fmaxf(x.x, x.y)), fmaxf(x.z, x.w));
+            }
+            z = rowbuf;
+        } else {
+            for (int v = tid; v < V; v += 256) mx = fmaxf(mx, z[v]);
+        }
         mx = wave_max(mx);
         __syncthreads();
         if ((tid & 63) == 0) red[tid >> 6] = mx;
@@ -173,42 +214,17 @@ __global__ __launch_bounds__(256) void beam_select_kernel(const float* __restric
         __syncthreads();
         if ((tid & 63) == 0) red[tid >> 6] = se;
         __syncthreads();
-        if (tid == 0) {
-            row_max[w] = mx;
-            row_logsum[w] = __logf((red[0] + red[1]) + (red[2] + red[3]));
-            row_score[w] = score_in[n * W + w];
-            row_fin[w] = fin_in[n * W + w];
-        }
+        const float logsum = __logf((red[0] + red[1]) + (red[2] + red[3]));
+        for (int v = tid; v < V; v += 256) offer(rscore + ((z[v] - mx) - logsum), w * V + v);
     }
     __syncthreads();
-    // 2. per-thread top-(MAXW+1) over its strided share of the W*V candidates (flat index ascending);
-    //    the list length is a compile-time constant so it stays in registers
-    Cand loc[MAXW + 1];
-#pragma unroll
-    for (int k = 0; k <= MAXW; ++k) loc[k] = Cand{-INFINITY, 0x7fffffff};
-    const int total = W * V;
-    for (int f = tid; f < total; f += 256) {
-        const int w = f / V, v = f - w * V;
-        float s;
-        if (row_fin[w]) s = row_score[w] + (v == TOK_PAD ? 0.f : NEG);
-        else s = row_score[w] + ((logits[(size_t)(n * W + w) * ldl + v] - row_max[w]) - row_logsum[w]);
-        const Cand c{s, f};
-        if (better(c, loc[MAXW])) {
-            loc[MAXW] = c;
-#pragma unroll
-            for (int k = MAXW; k > 0; --k)
-                if (better(loc[k], loc[k - 1])) {
-                    const Cand tmp = loc[k]; loc[k] = loc[k - 1]; loc[k - 1] = tmp;
-                }
-        }
-    }
     // 3. W+1 rounds of block-wide best: winner pops the head of its local list
     for (int k = 0; k <= W; ++k) {
         const Cand b = block_best(loc[0], sh);
         if (loc[0].i == b.i && loc[0].s == b.s) {
 #pragma unroll
-            for (int q = 0; q < MAXW; ++q) loc[q] = loc[q + 1];
-            loc[MAXW] = Cand{-INFINITY, 0x7fffffff};
+            for (int q = 0; q < LW - 1; ++q) loc[q] = loc[q + 1];
+            loc[LW - 1] = Cand{-INFINITY, 0x7fffffff};
         }
         if (tid == 0) picked[k] = b;
         __syncthreads();
@@ -372,9 +388,37 @@ extern "C" int capdec_beam_select(const void* logits, int ldl, const void* score
     CAPDEC_REQUIRE(N > 0 && W >= 1 && W <= MAXW && V >= W + 1 && ldl >= V && t >= 0 && t < Tmax,
                    "capdec_beam_select: bad shape N=%d W=%d (max %d) V=%d t=%d Tmax=%d", N, W, MAXW, V, t, Tmax);
     CAPDEC_REQUIRE((uint64_t)W * V < (1ull << 31), "capdec_beam_select: W*V too large");
-    hipLaunchKernelGGL(beam_select_kernel, dim3(N), dim3(256), 0, (hipStream_t)stream, (const float*)logits, ldl,
-                       (const float*)score_in, (float*)score_out, fin_in, fin_out, anc_in, anc_out, seq_in, seq_out,
-                       next_tok, (float*)gap, W, V, Tmax, t);
+    // rows that can be staged in LDS (float4-readable, at most 144 KB) take the one-read kernel
+    const size_t lds = (size_t)V * sizeof(float);
+    bool stage = V % 4 == 0 && ldl % 4 == 0 && aligned16(logits) && lds <= 144 * 1024;
+    if (stage && lds > 48 * 1024) {
+        static bool configured[64] = {};
+        int dev = 0;
+        if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) return CAPDEC_ERR_LAUNCH;
+        if (!configured[dev]) {
+            const void* fns[4] = {reinterpret_cast<const void*>(&beam_select_kernel<true, 2>),
+                                  reinterpret_cast<const void*>(&beam_select_kernel<true, 4>),
+                                  reinterpret_cast<const void*>(&beam_select_kernel<true, 6>),
+                                  reinterpret_cast<const void*>(&beam_select_kernel<true, MAXW + 1>)};
+            for (const void* fn : fns)
+                if (hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, 144 * 1024) != hipSuccess) stage = false;
+            configured[dev] = stage;
+        }
+    }
+#define CAPDEC_BEAM(ST, LW) \
+    hipLaunchKernelGGL((beam_select_kernel<ST, LW>), dim3(N), dim3(256), ST ? lds : 0, (hipStream_t)stream, \
+                       (const float*)logits, ldl, (const float*)score_in, (float*)score_out, fin_in, fin_out, anc_in, \
+                       anc_out, seq_in, seq_out, next_tok, (float*)gap, W, V, Tmax, t)
+    if (stage) {
+        if (W <= 1) CAPDEC_BEAM(true, 2);
+        else if (W <= 3) CAPDEC_BEAM(true, 4);
+        else if (W <= 5) CAPDEC_BEAM(true, 6);
+        else CAPDEC_BEAM(true, MAXW + 1);
+    } else {
+        if (W <= 3) CAPDEC_BEAM(false, 4);
+        else CAPDEC_BEAM(false, MAXW + 1);
+    }
+#undef CAPDEC_BEAM
     return check_launch("capdec_beam_select");
 }
 

@@ -204,3 +204,58 @@ def test_sampler_draw_frequencies_follow_the_top5_distribution():
     assert int(counts.sum()) == n  # never outside the top-5
     chi2 = float((((counts - n * probs) ** 2) / (n * probs)).sum())
     assert chi2 < 23.5, (chi2, counts.tolist(), (n * probs).tolist())
+
+
+@pytest.mark.parametrize("N,W,V,t", [(7, 3, 10000, 4), (5, 5, 1000, 0), (3, 1, 36, 2), (2, 8, 30000, 7), (4, 3, 40004, 1)])
+def test_beam_select_kernel_against_torch_topk_and_row_staging_is_bit_identical(N, W, V, t):
+    """capdec_beam_select through the C-ABI: top-W of score + log_softmax over W*V candidates (score desc,
+    flat index asc), finished beams continue with PAD only, ancestry / sequence tables rewritten.  The
+    LDS-staged variant (16-byte aligned rows) and the re-reading one (ldl = V + 1) must agree bit for bit."""
+    from imagecaption_amd._capi import lib, check, ptr, stream
+    g = torch.Generator().manual_seed(N * 1000 + V)
+    Tmax = 9
+    logits = (torch.randn(N * W, V, generator=g) * 3).to(DEV)
+    score = (torch.randn(N, W, generator=g) * 2).to(DEV)
+    fin = (torch.rand(N * W, generator=g) < 0.3).to(torch.int32).to(DEV)
+    if t == 0:
+        score[:, 1:] = -1.0e30
+        fin.zero_()
+    anc = torch.randint(0, N * W, (N * W, Tmax), generator=g).to(torch.int32).to(DEV)
+    seq = torch.randint(0, V, (N * W, Tmax), generator=g).to(torch.int32).to(DEV)
+
+    def run(lg):
+        so, fo = torch.empty_like(score), torch.empty_like(fin)
+        ao, qo = torch.zeros_like(anc), torch.zeros_like(seq)
+        tok = torch.empty(N * W, dtype=torch.int64, device=DEV)
+        gap = torch.full((N,), float("inf"), device=DEV)
+        check(lib().capdec_beam_select(ptr(lg), lg.stride(0), ptr(score), ptr(so), ptr(fin), ptr(fo), ptr(anc), ptr(ao),
+                                       ptr(seq), ptr(qo), ptr(tok), ptr(gap), N, W, V, Tmax, t, stream()), "beam_select")
+        torch.cuda.synchronize()
+        return so, fo, ao, qo, tok, gap
+
+    a = run(logits)                                              # rows 16-byte aligned: staged when V % 4 == 0
+    padded = torch.empty(N * W, V + 1, device=DEV)
+    padded[:, :V] = logits
+    b = run(padded[:, :V])                                       # ldl = V + 1: the re-reading kernel
+    for x, y in zip(a, b):
+        assert torch.equal(x, y)
+    so, fo, ao, qo, tok, gap = a
+    lp = torch.log_softmax(logits.double(), dim=-1).view(N, W, V)
+    cand = score.double().view(N, W, 1) + lp
+    finm = fin.view(N, W).bool()
+    padonly = torch.full((V,), -1.0e30, dtype=torch.float64, device=DEV)
+    padonly[0] = 0.0
+    cand = torch.where(finm.view(N, W, 1), score.double().view(N, W, 1) + padonly, cand).view(N, W * V)
+    top = cand.topk(W + 1, dim=1)
+    for n in range(N):
+        margin = float((top.values[n, :-1] - top.values[n, 1:]).min())
+        if margin < 1e-4:
+            continue                                              # near tie in fp32: order not pinned by the double reference
+        idx = top.indices[n, :W]
+        pw, tk = idx // V, idx % V
+        assert torch.equal(tok[n * W:(n + 1) * W].cpu(), tk.cpu())
+        assert torch.allclose(so[n].double(), top.values[n, :W], rtol=1e-5, atol=1e-4)
+        rows = n * W + pw
+        assert torch.equal(ao[n * W:(n + 1) * W, t].long().cpu(), rows.cpu())
+        assert torch.equal(qo[n * W:(n + 1) * W, :t].cpu(), seq[rows, :t].cpu())
+        assert torch.equal(fo[n * W:(n + 1) * W].bool().cpu(), (finm.view(-1)[rows] | (tk == 2)).cpu())

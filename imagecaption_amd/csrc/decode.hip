@@ -20,6 +20,52 @@ struct DecodeAttnParams {
     float scale;
 };
 
+// Online-softmax state of one (row, head) and its update by one pass of 64/LPK keys.  Every
+// operation is spelled with an explicit rounding intrinsic, so the compiler cannot contract it
+// differently in the two kernels below: a hypothesis gets the same bits whatever the beam width.
+struct RowAttn {
+    float m, l;
+    float4 acc;
+};
+template <int LPK>
+__device__ __forceinline__ void row_attn_update(RowAttn& st, const float4& q4, const float4& k4, const float4& v4, bool valid) {
+    float s = __fadd_rn(__fmaf_rn(q4.x, k4.x, __fmul_rn(q4.y, k4.y)), __fmaf_rn(q4.z, k4.z, __fmul_rn(q4.w, k4.w)));
+#pragma unroll
+    for (int o = 1; o < LPK; o <<= 1) s = __fadd_rn(s, __shfl_xor(s, o, 64));
+    s = valid ? s : -INFINITY;
+    float mi = s;
+#pragma unroll
+    for (int o = LPK; o < 64; o <<= 1) mi = fmaxf(mi, __shfl_xor(mi, o, 64));
+    const float mn = fmaxf(st.m, mi);  // finite: key 0 is always valid in the first pass
+    const float alpha = __expf(__fsub_rn(st.m, mn));
+    const float pj = valid ? __expf(__fsub_rn(s, mn)) : 0.f;
+    float ps = pj;
+#pragma unroll
+    for (int o = LPK; o < 64; o <<= 1) ps = __fadd_rn(ps, __shfl_xor(ps, o, 64));
+    st.l = __fmaf_rn(st.l, alpha, ps);
+    st.acc.x = __fmaf_rn(st.acc.x, alpha, __fmul_rn(pj, v4.x));
+    st.acc.y = __fmaf_rn(st.acc.y, alpha, __fmul_rn(pj, v4.y));
+    st.acc.z = __fmaf_rn(st.acc.z, alpha, __fmul_rn(pj, v4.z));
+    st.acc.w = __fmaf_rn(st.acc.w, alpha, __fmul_rn(pj, v4.w));
+    st.m = mn;
+}
+template <int LPK>
+__device__ __forceinline__ float4 row_attn_finish(RowAttn& st) {
+#pragma unroll
+    for (int o = LPK; o < 64; o <<= 1) {
+        st.acc.x = __fadd_rn(st.acc.x, __shfl_xor(st.acc.x, o, 64));
+        st.acc.y = __fadd_rn(st.acc.y, __shfl_xor(st.acc.y, o, 64));
+        st.acc.z = __fadd_rn(st.acc.z, __shfl_xor(st.acc.z, o, 64));
+        st.acc.w = __fadd_rn(st.acc.w, __shfl_xor(st.acc.w, o, 64));
+    }
+    const float inv = __fdiv_rn(1.f, st.l);
+    return make_float4(__fmul_rn(st.acc.x, inv), __fmul_rn(st.acc.y, inv), __fmul_rn(st.acc.z, inv), __fmul_rn(st.acc.w, inv));
+}
+__device__ __forceinline__ float4 scaled_q(const float* ptr, float scale) {
+    float4 q4 = *reinterpret_cast<const float4*>(ptr);
+    return make_float4(__fmul_rn(q4.x, scale), __fmul_rn(q4.y, scale), __fmul_rn(q4.z, scale), __fmul_rn(q4.w, scale));
+}
+
 // one wave per (row, head); LPK = DH/4 lanes share one key (float4 each), 64/LPK keys per pass.
 template <int DH>
 __global__ __launch_bounds__(256) void decode_attn_kernel(DecodeAttnParams p) {
@@ -30,10 +76,8 @@ __global__ __launch_bounds__(256) void decode_attn_kernel(DecodeAttnParams p) {
     const int r = item / p.H, h = item % p.H;
     const int g = lane / LPK, e4 = lane % LPK;
     const int nkeys = p.anc ? p.t + 1 : p.S;
-    float4 q4 = *reinterpret_cast<const float4*>(p.q + (size_t)r * p.ldq + h * DH + e4 * 4);
-    q4.x *= p.scale; q4.y *= p.scale; q4.z *= p.scale; q4.w *= p.scale;
-    float m = -INFINITY, l = 0.f;
-    float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+    const float4 q4 = scaled_q(p.q + (size_t)r * p.ldq + h * DH + e4 * 4, p.scale);
+    RowAttn st{-INFINITY, 0.f, make_float4(0.f, 0.f, 0.f, 0.f)};
     for (int j0 = 0; j0 < nkeys; j0 += KPI) {
         const int j = j0 + g;
         const bool valid = j < nkeys;
@@ -51,33 +95,47 @@ __global__ __launch_bounds__(256) void decode_attn_kernel(DecodeAttnParams p) {
             k4 = *reinterpret_cast<const float4*>(p.k + row * p.ldkv + h * DH + e4 * 4);
             v4 = *reinterpret_cast<const float4*>(p.v + row * p.ldkv + h * DH + e4 * 4);
         }
-        float s = (q4.x * k4.x + q4.y * k4.y) + (q4.z * k4.z + q4.w * k4.w);
+        row_attn_update<LPK>(st, q4, k4, v4, valid);
+    }
+    const float4 o4 = row_attn_finish<LPK>(st);
+    if (g == 0) *reinterpret_cast<float4*>(p.out + (size_t)r * p.ldo + h * DH + e4 * 4) = o4;
+}
+
+// Cross attention for beams: the NB hypotheses of one image attend the SAME per-image K/V, so one
+// wave serves all NB rows of an (image, head) and reads each key / value once (the per-row kernel
+// above reads them NB times; L2 absorbs that, but the CU-side delivery rate is what bounds it).
+template <int DH, int NB>
+__global__ __launch_bounds__(256) void decode_cross_attn_kernel(DecodeAttnParams p) {
+    constexpr int LPK = DH / 4, KPI = 64 / LPK;
+    const int lane = threadIdx.x & 63;
+    const int item = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (item >= (p.R / NB) * p.H) return;
+    const int n = item / p.H, h = item % p.H;
+    const int g = lane / LPK, e4 = lane % LPK;
+    float4 q4[NB];
+    RowAttn st[NB];
 #pragma unroll
-        for (int o = 1; o < LPK; o <<= 1) s += __shfl_xor(s, o, 64);
-        s = valid ? s : -INFINITY;
-        float mi = s;
+    for (int b = 0; b < NB; ++b) {
+        q4[b] = scaled_q(p.q + (size_t)(n * NB + b) * p.ldq + h * DH + e4 * 4, p.scale);
+        st[b] = RowAttn{-INFINITY, 0.f, make_float4(0.f, 0.f, 0.f, 0.f)};
+    }
+    const float* kb = p.k + (size_t)n * p.S * p.ldkv + h * DH + e4 * 4;
+    const float* vb = p.v + (size_t)n * p.S * p.ldkv + h * DH + e4 * 4;
+    for (int j0 = 0; j0 < p.S; j0 += KPI) {
+        const int j = j0 + g;
+        const bool valid = j < p.S;
+        float4 k4 = make_float4(0.f, 0.f, 0.f, 0.f), v4 = k4;
+        if (valid) {
+            k4 = *reinterpret_cast<const float4*>(kb + (size_t)j * p.ldkv);
+            v4 = *reinterpret_cast<const float4*>(vb + (size_t)j * p.ldkv);
+        }
 #pragma unroll
-        for (int o = LPK; o < 64; o <<= 1) mi = fmaxf(mi, __shfl_xor(mi, o, 64));
-        const float mn = fmaxf(m, mi);  // finite: key 0 is always valid in the first pass
-        const float alpha = __expf(m - mn);
-        const float pj = valid ? __expf(s - mn) : 0.f;
-        float ps = pj;
-#pragma unroll
-        for (int o = LPK; o < 64; o <<= 1) ps += __shfl_xor(ps, o, 64);
-        l = l * alpha + ps;
-        acc.x = acc.x * alpha + pj * v4.x; acc.y = acc.y * alpha + pj * v4.y;
-        acc.z = acc.z * alpha + pj * v4.z; acc.w = acc.w * alpha + pj * v4.w;
-        m = mn;
+        for (int b = 0; b < NB; ++b) row_attn_update<LPK>(st[b], q4[b], k4, v4, valid);
     }
 #pragma unroll
-    for (int o = LPK; o < 64; o <<= 1) {
-        acc.x += __shfl_xor(acc.x, o, 64); acc.y += __shfl_xor(acc.y, o, 64);
-        acc.z += __shfl_xor(acc.z, o, 64); acc.w += __shfl_xor(acc.w, o, 64);
-    }
-    if (g == 0) {
-        const float inv = 1.f / l;
-        *reinterpret_cast<float4*>(p.out + (size_t)r * p.ldo + h * DH + e4 * 4) =
-            make_float4(acc.x * inv, acc.y * inv, acc.z * inv, acc.w * inv);
+    for (int b = 0; b < NB; ++b) {
+        const float4 o4 = row_attn_finish<LPK>(st[b]);
+        if (g == 0) *reinterpret_cast<float4*>(p.out + (size_t)(n * NB + b) * p.ldo + h * DH + e4 * 4) = o4;
     }
 }
 
@@ -364,6 +422,18 @@ extern "C" int capdec_decode_attn(const void* q, int ldq, const void* k, const v
     p.scale = scale;
     const dim3 grid((R * H + 3) / 4);
     hipStream_t st = (hipStream_t)stream;
+    if (!anc && W > 1 && W <= 8 && R % W == 0) {  // beams of one image share its K/V: one wave per (image, head)
+        const dim3 gx(((R / W) * H + 3) / 4);
+#define CAPDEC_X(D, NB) hipLaunchKernelGGL((decode_cross_attn_kernel<D, NB>), gx, dim3(256), 0, st, p)
+#define CAPDEC_XW(D) \
+    switch (W) { case 2: CAPDEC_X(D, 2); break; case 3: CAPDEC_X(D, 3); break; case 4: CAPDEC_X(D, 4); break; \
+                 case 5: CAPDEC_X(D, 5); break; case 6: CAPDEC_X(D, 6); break; case 7: CAPDEC_X(D, 7); break; \
+                 default: CAPDEC_X(D, 8); break; }
+        if (dh == 32) { CAPDEC_XW(32) } else if (dh == 64) { CAPDEC_XW(64) } else { CAPDEC_XW(128) }
+#undef CAPDEC_XW
+#undef CAPDEC_X
+        return check_launch("capdec_decode_attn");
+    }
     if (dh == 32) hipLaunchKernelGGL(decode_attn_kernel<32>, grid, dim3(256), 0, st, p);
     else if (dh == 64) hipLaunchKernelGGL(decode_attn_kernel<64>, grid, dim3(256), 0, st, p);
     else hipLaunchKernelGGL(decode_attn_kernel<128>, grid, dim3(256), 0, st, p);

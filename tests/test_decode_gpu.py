@@ -259,3 +259,35 @@ def test_beam_select_kernel_against_torch_topk_and_row_staging_is_bit_identical(
         assert torch.equal(ao[n * W:(n + 1) * W, t].long().cpu(), rows.cpu())
         assert torch.equal(qo[n * W:(n + 1) * W, :t].cpu(), seq[rows, :t].cpu())
         assert torch.equal(fo[n * W:(n + 1) * W].bool().cpu(), (finm.view(-1)[rows] | (tk == 2)).cpu())
+
+
+@pytest.mark.parametrize("N,W,H,dh,S", [(5, 3, 8, 64, 49), (3, 5, 2, 32, 7), (2, 8, 4, 128, 196), (4, 2, 8, 64, 1)])
+def test_cross_decode_attention_shared_by_beams_is_bit_identical_to_per_row(N, W, H, dh, S):
+    """capdec_decode_attn, cross mode: the W beams of an image read its K/V once (one wave per image and
+    head).  Must equal, bit for bit, the per-row kernel run on K/V replicated per beam, and a float64
+    softmax(q k^T / sqrt(dh)) v within fp32 rounding."""
+    import math
+    from imagecaption_amd._capi import lib, check, ptr, stream
+    g = torch.Generator().manual_seed(N * 10 + W)
+    d, R = H * dh, N * W
+    q = torch.randn(R, d, generator=g).to(DEV)
+    kv = torch.randn(N * S, 2 * d, generator=g).to(DEV)
+    scale = 1.0 / math.sqrt(dh)
+
+    def run(kvt, w):
+        out = torch.empty(R, d, device=DEV)
+        check(lib().capdec_decode_attn(ptr(q), d, ptr(kvt), ptr(kvt[:, d:]), 2 * d, ptr(out), d, None, R, H, dh, 1, 0, w, S,
+                                       scale, stream()), "decode_attn")
+        torch.cuda.synchronize()
+        return out
+
+    shared = run(kv, W)
+    rep = kv.view(N, 1, S, 2 * d).expand(N, W, S, 2 * d).reshape(R * S, 2 * d).contiguous()
+    per_row = run(rep, 1)
+    assert torch.equal(shared, per_row)
+    qh = q.double().view(N, W, H, dh)
+    k = kv[:, :d].double().view(N, S, H, dh)
+    v = kv[:, d:].double().view(N, S, H, dh)
+    p = torch.softmax(torch.einsum("nwhe,nshe->nwhs", qh, k) * scale, dim=-1)
+    ref = torch.einsum("nwhs,nshe->nwhe", p, v).reshape(R, d)
+    assert float((shared.double() - ref).abs().max()) < 2e-5

@@ -120,11 +120,17 @@ def decode_bench(model, cfg, dev, rank, world, dtype="fp32", images=4096, max_le
         res[f"{name}_captions_per_sec"] = images * world / dt
         W = {"beam3": 3, "beam5": 5}.get(name, 1)
         tf = decode_flops_per_image(cfg, W, max_len) * images / dt / 1e12  # per GPU (dt is the slowest rank's)
-        peak = PEAK_F32_MFMA_TFLOPS if dtype == "fp32" else PEAK_BF16_MFMA_TFLOPS
+        peak = mfma_peak(dtype)
         res[f"{name}_roofline"] = {"bound": "mfma", "achieved": tf, "peak": peak, "unit": "TFLOP/s", "frac": tf / peak}
     res["images_per_gpu"], res["max_len"] = images, max_len
     model.train()
     return res
+
+
+def mfma_peak(dtype):
+    """Dense matrix peak in ALGORITHMIC (2*M*N*K) TFLOP/s: the split-fp32 mode issues six bf16 products per
+    fp32 product, so its ceiling is the bf16 peak / 6."""
+    return {"fp32": PEAK_F32_MFMA_TFLOPS, "bf16": PEAK_BF16_MFMA_TFLOPS, "f32x3": PEAK_BF16_MFMA_TFLOPS / 6.0}[dtype]
 
 
 def measured_mfma_peak(dtype):
@@ -278,13 +284,13 @@ def main():
         attn = {k: a for k, a in agg.items() if k.startswith("attn")}
         attn_b = sum(a[2] for a in attn.values())
         attn_t = sum(a[3] for a in attn.values())
-        peak = PEAK_F32_MFMA_TFLOPS if args.dtype == "fp32" else PEAK_BF16_MFMA_TFLOPS
+        peak = mfma_peak(args.dtype)
         vk = f"gemm_nt_{cfg['batch'] * cfg['T']}x{cfg['vocab']}x{2 * cfg['d']}"
         vocab = detail.get(vk)
         out = {
             "metric": "train_images_per_sec", "value": value, "unit": "images/s", "n_gpus": world,
             "steps": args.steps, "warmup": args.warmup, "ms_per_step": ms, "higher_is_better": True,
-            "scaling": "weak", "vs_baseline": None, "dtype": "f32" if args.dtype == "fp32" else "bf16", "data": "synthetic",
+            "scaling": "weak", "vs_baseline": None, "dtype": {"fp32": "f32", "f32x3": "f32 (3 x bf16 split operands, six bf16 MFMA products)", "bf16": "bf16"}[args.dtype], "data": "synthetic",
             "config": {"workload": f"BASELINE.json configs[1] (C2): 7x7x2048 grid features, hidden {cfg['d']}, "
                                    f"{cfg['layers']} layers, vocab {cfg['vocab']}, len {cfg['T']}, batch "
                                    f"{cfg['batch']}/GPU, teacher-forced train step incl. dropout, clip, AdamW"
@@ -297,9 +303,9 @@ def main():
             "roofline": ({"bound": "mfma", "achieved": vocab[1] / vocab[3] / 1e12, "peak": peak,
                           "unit": "TFLOP/s", "frac": vocab[1] / vocab[3] / 1e12 / peak,
                           "traffic": vocab_traffic(args.config) if args.dtype == "fp32" else None,
-                          "kernel": f"gemm_{'f32' if args.dtype == 'fp32' else 'bf16'}_kernel, vocab projection forward {vk[8:]} (one launch per step)",
+                          "kernel": f"gemm_{ {'fp32': 'f32', 'f32x3': 'f32x3', 'bf16': 'bf16'}[args.dtype] }_kernel, vocab projection forward {vk[8:]} (one launch per step)",
                           "ms": vocab[3] * 1e3 / vocab[0],
-                          "peak_measured": measured_mfma_peak("fp32" if args.dtype == "fp32" else "bf16")} if vocab else None),
+                          "peak_measured": measured_mfma_peak("fp32" if args.dtype == "fp32" else "bf16") / (6.0 if args.dtype == "f32x3" else 1.0)} if vocab else None),
             "gemm_all": {"bound": "mfma", "achieved": ach, "peak": peak, "unit": "TFLOP/s",
                          "frac": ach / peak, "launches_per_step": gemm_n,
                          "ms_per_step": gemm_time * 1e3},

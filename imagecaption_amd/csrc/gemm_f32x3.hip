@@ -11,9 +11,15 @@
 // gemm_f32.hip (tests/test_ops_gpu.py compares both against float64) at 16/6 = 2.7x its matrix rate.
 // Non-finite operands come out as NaN (inf - inf in the residual), finite data is unaffected.
 //
-// Block tile BM x BN x 32, 512 threads: four consumer waves (2 x 2 over the tile, one per SIMD) run the
-// MFMA chain, four producer waves (their SIMD partners) load, split and store the next k-tile;
-// double-buffered LDS (dynamic, up to 120 KiB), one s_barrier per k-tile.
+// Block tile BM x BN x 32, 256 threads (2 x 2 waves over the tile): every wave loads, splits, stores
+// AND multiplies -- the structure of gemm_bf16.hip with three planes and six products.  One LDS buffer
+// (dynamic, 30-60 KiB) plus a register stage; the split / store phase of one workgroup is covered by
+// the MFMAs of the other workgroups resident on the CU (2 at 128x128, 3 at 128x64, 4 at 64x64).
+// (A first version with four dedicated producer waves feeding four consumer waves was 5-25 % slower
+// at every shape: one MFMA-issuing wave per SIMD cannot hide its own LDS read latency.)
+// What bounds it (PMC, vocab projection, 128x128): 5.7 vector instructions per MFMA -- the split is
+// redone by every workgroup that touches an element -- against the ~6 that fit in an MFMA's shadow,
+// so the matrix pipe is busy 41 % of the time: 150-165 TFLOP/s fp32-equivalent on large products.
 // LDS images, three bf16 planes per operand:
 //   k-contiguous operand  : [row][40]   (80-B rows)  -> fragment = one ds_read_b128, conflict-free
 //   row-contiguous operand: [k][rows+32] (rows*2+64 B per k) -> written as loaded (no register
@@ -67,11 +73,11 @@ __device__ __forceinline__ bf16x4 lds_read_tr(const __bf16* ptr) {
     return __builtin_bit_cast(bf16x4, v);
 }
 
-// one operand: global -> registers -> three-plane LDS image (producer waves); fragment reads (consumers)
+// one operand: global -> registers -> three-plane LDS image; fragment reads
 template <int ROWS, bool KC, bool VEC>
 struct Operand {
-    static constexpr int NT = 256;                                    // producer threads
-    static constexpr int REGS = ROWS * XBK / 4 / NT;                  // float4 per producer thread per k-tile
+    static constexpr int NT = 256;                                    // threads per workgroup
+    static constexpr int REGS = ROWS * XBK / 4 / NT;                  // float4 per thread per k-tile
     static constexpr int LD = KC ? XLDK : ROWS + XPAD;                // image row stride (bf16 elements)
     static constexpr int PLANE = KC ? ROWS * XLDK : XBK * (ROWS + XPAD);
     static constexpr int RQ = ROWS / 4;
@@ -124,79 +130,15 @@ struct Operand {
     }
 };
 
-// Producer waves (4..7): stream k-tiles HBM -> registers -> split -> LDS.  The LDS image runs one
-// tile ahead of the consumers; two more tiles are in flight in two register stages.  The steady-state
-// loop is branch-free (tile indices past the end are clamped: loaded again, stored to a buffer nobody
-// reads any more) so that the compiler can count outstanding loads and wait for the older stage only.
-// One s_barrier per k-tile, matched by the consumers.
-template <int BM, int BN, bool AK, bool BKM, bool VEC, bool INTERIOR, bool COLSUM>
-__device__ __forceinline__ void x3_produce(const GemmParams& p, __bf16* smem, int m0, int n0, int kbeg, int kend, int nk,
-                                           int ptid) {
-    typedef Operand<BM, AK, VEC> OA;
-    typedef Operand<BN, BKM, VEC> OB;
-    constexpr int BUF = 3 * (OA::PLANE + OB::PLANE);
-    float4 ra0[OA::REGS], rb0[OB::REGS], ra1[OA::REGS], rb1[OB::REGS];
-    float csum = 0.f;
-    auto fetch = [&](float4* ra, float4* rb, int kt) {
-        const int k0 = kbeg + min(kt, nk - 1) * XBK;
-        OA::template gload<INTERIOR>(ra, p.A, p.lda, m0, p.M, k0, kend, ptid);
-        OB::template gload<INTERIOR>(rb, p.B, p.ldb, n0, p.N, k0, kend, ptid);
-    };
-    auto stash = [&](const float4* ra, const float4* rb, int kt) {  // tile kt -> LDS buffer kt & 1
-        __bf16* An = smem + (kt & 1) * BUF;
-        OA::lstore(ra, An, ptid);
-        OB::lstore(rb, An + 3 * OA::PLANE, ptid);
-    };
-    auto colsum_of = [&](int kt) {  // A image is [k][m]; the three planes sum to the fp32 value exactly
-        if (COLSUM && ptid < BM) {
-            const __bf16* As = smem + (kt & 1) * BUF;
-#pragma unroll 8
-            for (int k = 0; k < XBK; ++k)
-                csum += ((float)As[k * OA::LD + ptid] + (float)As[OA::PLANE + k * OA::LD + ptid]) +
-                        (float)As[2 * OA::PLANE + k * OA::LD + ptid];
-        }
-    };
-    if (nk <= 0) {
-        __syncthreads();
-        return;
-    }
-    fetch(ra0, rb0, 0);
-    fetch(ra1, rb1, 1);
-    stash(ra0, rb0, 0);
-    fetch(ra0, rb0, 2);
-    __syncthreads();
-    // entering iteration kt (even): tile kt+1 is in stage 1, tile kt+2 in stage 0
-    int kt = 0;
-    for (; kt + 1 < nk; kt += 2) {
-        stash(ra1, rb1, kt + 1);
-        fetch(ra1, rb1, kt + 3);
-        colsum_of(kt);
-        __syncthreads();
-        stash(ra0, rb0, kt + 2);
-        fetch(ra0, rb0, kt + 4);
-        colsum_of(kt + 1);
-        __syncthreads();
-    }
-    if (kt < nk) {  // odd tile count: the last tile is already in LDS
-        colsum_of(kt);
-        __syncthreads();
-    }
-    if (COLSUM && ptid < BM && m0 + ptid < p.M) {
-        if (gridDim.z > 1) p.ws_colsum[(size_t)blockIdx.z * p.M + m0 + ptid] = csum;
-        else p.colsum[m0 + ptid] = csum;
-    }
-}
-
-// 512 threads: waves 0..3 multiply (2 x 2 over the block tile, one per SIMD), waves 4..7 feed them.
-// A SIMD's consumer and producer wave issue side by side: the matrix pipe runs the consumer's MFMA
-// chain while the producer's loads, splits and LDS stores use the vector / memory issue slots.
 template <int BM, int BN, bool AK, bool BKM, bool VEC>
-__global__ __launch_bounds__(512) void gemm_f32x3_kernel(GemmParams p) {
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(BM * BN >= 128 * 128 ? 2 : (BM * BN >= 128 * 64 ? 3 : 4))))
+void gemm_f32x3_kernel(GemmParams p) {
     typedef Operand<BM, AK, VEC> OA;
     typedef Operand<BN, BKM, VEC> OB;
     constexpr int TM = BM / 64, TN = BN / 64;
-    constexpr int BUF = 3 * (OA::PLANE + OB::PLANE);
     extern __shared__ __attribute__((aligned(16))) __bf16 x3_smem[];
+    __bf16* As = x3_smem;
+    __bf16* Bs = As + 3 * OA::PLANE;
 
     const int tid = threadIdx.x;
     const int lane = tid & 63, wave = tid >> 6;
@@ -220,20 +162,8 @@ __global__ __launch_bounds__(512) void gemm_f32x3_kernel(GemmParams p) {
     const int kbeg = blockIdx.z * p.ksplit;
     const int kend = min(p.K, kbeg + p.ksplit);
     const int nk = (kend - kbeg + XBK - 1) / XBK;
-
-    if (wave >= 4) {
-        const bool interior = VEC && (m0 + BM <= p.M) && (n0 + BN <= p.N) && ((kend - kbeg) % XBK == 0);
-        const bool do_colsum = (!AK) && p.colsum != nullptr && tile_n == 0;
-        const int ptid = tid - 256;
-        if (do_colsum) {
-            if (interior) x3_produce<BM, BN, AK, BKM, VEC, true, !AK>(p, x3_smem, m0, n0, kbeg, kend, nk, ptid);
-            else x3_produce<BM, BN, AK, BKM, VEC, false, !AK>(p, x3_smem, m0, n0, kbeg, kend, nk, ptid);
-        } else {
-            if (interior) x3_produce<BM, BN, AK, BKM, VEC, true, false>(p, x3_smem, m0, n0, kbeg, kend, nk, ptid);
-            else x3_produce<BM, BN, AK, BKM, VEC, false, false>(p, x3_smem, m0, n0, kbeg, kend, nk, ptid);
-        }
-        return;
-    }
+    const bool interior = VEC && (m0 + BM <= p.M) && (n0 + BN <= p.N) && ((kend - kbeg) % XBK == 0);
+    const bool do_colsum = (!AK) && p.colsum != nullptr && tile_n == 0;
 
     const int l31 = lane & 31, half = lane >> 5;
     const int wrow = (wave >> 1) * (BM / 2), wcol = (wave & 1) * (BN / 2);
@@ -245,10 +175,26 @@ __global__ __launch_bounds__(512) void gemm_f32x3_kernel(GemmParams p) {
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f, cor[i][j][r] = 0.f;
 
+    float4 ra[OA::REGS], rb[OB::REGS];
+    float csum = 0.f;
+    auto fetch = [&](int kt) {
+        const int k0 = kbeg + kt * XBK;
+        if (interior) {
+            OA::template gload<true>(ra, p.A, p.lda, m0, p.M, k0, kend, tid);
+            OB::template gload<true>(rb, p.B, p.ldb, n0, p.N, k0, kend, tid);
+        } else {
+            OA::template gload<false>(ra, p.A, p.lda, m0, p.M, k0, kend, tid);
+            OB::template gload<false>(rb, p.B, p.ldb, n0, p.N, k0, kend, tid);
+        }
+    };
+    if (nk > 0) {
+        fetch(0);
+        OA::lstore(ra, As, tid);
+        OB::lstore(rb, Bs, tid);
+    }
     __syncthreads();
     for (int kt = 0; kt < nk; ++kt) {
-        const __bf16* As = x3_smem + (kt & 1) * BUF;
-        const __bf16* Bs = As + 3 * OA::PLANE;
+        if (kt + 1 < nk) fetch(kt + 1);
 #pragma unroll
         for (int ks = 0; ks < XBK / 16; ++ks) {
             bf16x8 af[3][TM], bf[3][TN];
@@ -259,9 +205,6 @@ __global__ __launch_bounds__(512) void gemm_f32x3_kernel(GemmParams p) {
 #pragma unroll
                 for (int j = 0; j < TN; ++j) bf[pl][j] = OB::frag(Bs, pl, wcol + j * 32, ks, lane);
             }
-            // The five correction products (<= 2^-8 of the main term) have their own accumulator: their
-            // roundings are relative to a 256x smaller sum, and the main accumulator rounds once per
-            // 16 k instead of once per partial product.
 #pragma unroll
             for (int i = 0; i < TM; ++i)
 #pragma unroll
@@ -276,10 +219,25 @@ __global__ __launch_bounds__(512) void gemm_f32x3_kernel(GemmParams p) {
                     acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[0][i], bf[0][j], acc[i][j], 0, 0, 0);
                 }
         }
+        if (do_colsum && tid < BM) {  // A image is [k][m]; the three planes sum to the fp32 value exactly
+#pragma unroll 8
+            for (int k = 0; k < XBK; ++k)
+                csum += ((float)As[k * OA::LD + tid] + (float)As[OA::PLANE + k * OA::LD + tid]) +
+                        (float)As[2 * OA::PLANE + k * OA::LD + tid];
+        }
+        __syncthreads();
+        if (kt + 1 < nk) {
+            OA::lstore(ra, As, tid);
+            OB::lstore(rb, Bs, tid);
+        }
         __syncthreads();
     }
 
     const bool split = gridDim.z > 1;
+    if (do_colsum && tid < BM && m0 + tid < p.M) {
+        if (split) p.ws_colsum[(size_t)blockIdx.z * p.M + m0 + tid] = csum;
+        else p.colsum[m0 + tid] = csum;
+    }
     float* wsz = split ? p.ws + (size_t)blockIdx.z * p.M * p.N : nullptr;
 #pragma unroll
     for (int i = 0; i < TM; ++i)
@@ -300,7 +258,7 @@ __global__ __launch_bounds__(512) void gemm_f32x3_kernel(GemmParams p) {
 
 template <int BM, int BN, bool AK, bool BKM, bool VEC>
 static int launch_one(const GemmParams& p, dim3 grid, hipStream_t st) {
-    constexpr size_t lds = 2 * 3 * (size_t)(Operand<BM, AK, VEC>::PLANE + Operand<BN, BKM, VEC>::PLANE) * sizeof(__bf16);
+    constexpr size_t lds = 3 * (size_t)(Operand<BM, AK, VEC>::PLANE + Operand<BN, BKM, VEC>::PLANE) * sizeof(__bf16);
     static bool configured[64] = {};
     int dev = 0;
     if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) return CAPDEC_ERR_LAUNCH;
@@ -312,7 +270,7 @@ static int launch_one(const GemmParams& p, dim3 grid, hipStream_t st) {
         }
         configured[dev] = true;
     }
-    hipLaunchKernelGGL((gemm_f32x3_kernel<BM, BN, AK, BKM, VEC>), grid, dim3(512), lds, st, p);
+    hipLaunchKernelGGL((gemm_f32x3_kernel<BM, BN, AK, BKM, VEC>), grid, dim3(256), lds, st, p);
     return CAPDEC_OK;
 }
 
@@ -341,27 +299,35 @@ GemmPlan plan_gemm_f32x3(int M, int N, int K) {
         if (bm == 64 && bn == 128) bm = 128, bn = 64;  // not instantiated; nearest
         return GemmPlan{bm, bn, XBK, cdiv(K, ks), ks};
     }
-    // calibrated on tools/gemm_sweep.py (SWEEP_DTYPE=f32x3, profiles/r01_gemm_sweep_f32x3.txt).  The product is
-    // bound by operand bytes per CU, so: short K (forward / input-gradient shapes) -> many 64x64 workgroups,
-    // two per CU, whose prologue / epilogue overlap; long K (weight gradients, the vocab input gradient)
-    // -> 128x128 tiles, K split until ~1000 workgroups are in flight or a slice gets shorter than 1024.
-    int bm = 64, bn = 64, split = 1;
-    if (K >= 4096) {
-        const long t128 = (long)cdiv(M, 128) * cdiv(N, 128);
-        if (t128 >= 32) {
-            bm = bn = 128;
-            while (t128 * split < 1024 && K / (split * 2) >= 1024 && split < 32) split *= 2;
-        } else {
-            const long t64 = (long)cdiv(M, 64) * cdiv(N, 64);
-            while (t64 * split < 1024 && K / (split * 2) >= 512 && split < 32) split *= 2;
+    // Cost model calibrated on tools/gemm_sweep.py (SWEEP_DTYPE=f32x3, profiles/r01_gemm_sweep_f32x3.txt):
+    // a CU holds `res` workgroups of a tile shape; a round of them costs res x (MFMA time of one
+    // workgroup) / eff, where eff (matrix-pipe utilisation) grows with the tile because the split work
+    // per MFMA shrinks; split-K adds its partial round trip.
+    static const struct { int bm, bn, res; double eff; } cand[3] = {{128, 128, 2, 0.47}, {128, 64, 3, 0.43}, {64, 64, 4, 0.37}};
+    GemmPlan best{64, 64, XBK, 1, cdiv(K, XBK) * XBK};
+    double best_cost = 1e300;
+    for (const auto& c : cand) {
+        const long tiles = (long)cdiv(M, c.bm) * cdiv(N, c.bn);
+        const double units = (c.bm / 64) * (c.bn / 64);
+        for (int split = 1; split <= 32; split *= 2) {
+            const int ks = cdiv(cdiv(K, split), XBK) * XBK;
+            if (split > 1 && ks < 256) break;
+            const int s_eff = cdiv(K, ks);
+            double rounds = (double)(tiles * s_eff) / (256.0 * c.res);
+            if (rounds < 4.0) {  // few rounds: a started round costs at least half a round
+                const double whole = (double)(long)rounds, frac = rounds - whole;
+                rounds = whole + (frac > 0.0 ? (frac > 0.5 ? frac : 0.5) : 0.0);
+                if (rounds < 1.0) rounds = 1.0;
+            }
+            double cost = rounds * c.res * units * 0.0928 * (ks / 16.0 + 4.0) / c.eff;  // microseconds
+            if (s_eff > 1) cost += (double)M * N * s_eff * 8.0 / 3.0e6 + 6.0;
+            if (cost < best_cost * 0.999) {
+                best_cost = cost;
+                best = GemmPlan{c.bm, c.bn, XBK, s_eff, ks};
+            }
         }
-    } else {
-        const long t64 = (long)cdiv(M, 64) * cdiv(N, 64);
-        while (t64 * split < 512 && K / (split * 2) >= 256 && split < 16) split *= 2;
-        if (split == 1 && t64 < 1024 && K >= 2048) split = 2;
     }
-    const int ks = cdiv(cdiv(K, split), XBK) * XBK;
-    return GemmPlan{bm, bn, XBK, cdiv(K, ks), ks};
+    return best;
 }
 
 int launch_gemm_f32x3(const GemmParams& p, const GemmPlan& pl, bool AK, bool BKM, bool vec, hipStream_t st) {

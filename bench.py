@@ -197,6 +197,46 @@ def profile_step(trainer, feats, ids, reps=3):
     return agg, detail
 
 
+def measured_hbm_copy_gbs():
+    """Read + write rate of a streaming copy of 1 GiB on THIS box (csrc/probe.hip), GB/s: what an
+    HBM-bound kernel can reach here, next to the nominal 8 TB/s the roofline fractions are quoted on."""
+    from imagecaption_amd._capi import check, lib, ptr, stream
+    n = 1 << 30
+    src = torch.empty(n, dtype=torch.uint8, device="cuda")
+    dst = torch.empty(n, dtype=torch.uint8, device="cuda")
+    src.zero_()
+    best = 0.0
+    for _ in range(3):
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        check(lib().capdec_probe_copy(ptr(src), ptr(dst), n, stream()), "capdec_probe_copy")
+        e1.record()
+        torch.cuda.synchronize()
+        best = max(best, 2.0 * n / (e0.elapsed_time(e1) * 1e-3) / 1e9)
+    return best
+
+
+def timed_steps(trainer, feats, ids, steps, warmup, world, dev):
+    """`warmup` untimed steps, then exactly `steps` steps between barrier + synchronize; MAX over ranks."""
+    for _ in range(warmup):
+        trainer.step(feats, ids)
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        loss = trainer.step(feats, ids)
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    if world > 1:
+        t = torch.tensor([dt], dtype=torch.float64, device=dev)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dt = float(t.item())
+    return dt, loss
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -212,6 +252,7 @@ def main():
     ap.add_argument("--no-side-streams", action="store_true", help="single-stream step (diagnostic)")
     ap.add_argument("--decode-images", type=int, default=4096, help="images per GPU for the decode leg")
     ap.add_argument("--detail", action="store_true", help="print the per-shape kernel table to stderr")
+    ap.add_argument("--no-modes", action="store_true", help="skip the f32x3 / bf16 legs of the default fp32 run")
     args = ap.parse_args()
     if os.environ.get("CAPDEC_HANG_DUMP"):  # debugging aid: dump every thread's stack after N seconds and exit
         import faulthandler
@@ -251,28 +292,28 @@ def main():
                              side_stream_wgrad=not args.no_side_streams)
     feats, ids = synth_batch(cfg, cfg["batch"], dev, rank)
 
-    for _ in range(args.warmup):
-        trainer.step(feats, ids)
-    if world > 1:
-        dist.barrier()
-    torch.cuda.synchronize()
-    t0 = time.perf_counter()
-    for _ in range(args.steps):
-        loss = trainer.step(feats, ids)
-    if world > 1:
-        dist.barrier()
-    torch.cuda.synchronize()
-    dt = time.perf_counter() - t0
-    if world > 1:
-        t = torch.tensor([dt], dtype=torch.float64, device=dev)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        dt = float(t.item())
+    dt, loss = timed_steps(trainer, feats, ids, args.steps, args.warmup, world, dev)
     loss_val = float(loss.item())
     decode = None if args.no_decode else decode_bench(model, cfg, dev, rank, world, dtype=args.dtype, images=args.decode_images,
                                                       max_len=min(cfg["T"], 20))
 
     # the instrumented step contains the gradient all-reduce: every rank must run it
     agg, detail = profile_step(trainer, feats, ids)
+    # the same step in the two optional arithmetic modes (never the headline `value`)
+    modes = {}
+    if args.dtype == "fp32" and not args.no_modes:
+        for mode in ("f32x3", "bf16"):
+            torch.manual_seed(42)
+            m2 = ImageCaptioningModel(cfg["vocab"], cfg["d"], cfg["heads"], cfg["layers"], feature_dim=cfg["din"]).to(dev)
+            m2.train()
+            t2 = CaptionTrainer(m2, dropout=0.0 if args.no_dropout else 0.1, seed=42, dtype=mode,
+                                side_stream_wgrad=not args.no_side_streams)
+            dt2, loss2 = timed_steps(t2, feats, ids, args.steps, args.warmup, world, dev)
+            modes[mode] = {"value": cfg["batch"] * world * args.steps / dt2, "unit": "images/s",
+                           "ms_per_step": dt2 / args.steps * 1e3, "loss": float(loss2.item()),
+                           "arithmetic": "fp32 operands split into 3 bf16 terms, six bf16 MFMA products, fp32-level accuracy"
+                           if mode == "f32x3" else "bf16 MFMA products, fp32 accumulate / storage / optimizer"}
+            del t2, m2
     out = None
     if rank == 0:
         ms = dt / args.steps * 1e3
@@ -298,6 +339,7 @@ def main():
                        "global_batch": cfg["batch"] * world, "seq_len": cfg["T"], "memory_len": cfg["S"],
                        "parallelism": f"dp{world}", "params": trainer.n_params},
             "loss": loss_val,
+            "modes": modes,
             "decode": decode,
             "step_tflops_algorithmic": train_flops_per_image(cfg) * value / 1e12,
             "roofline": ({"bound": "mfma", "achieved": vocab[1] / vocab[3] / 1e12, "peak": peak,
@@ -311,7 +353,8 @@ def main():
                          "ms_per_step": gemm_time * 1e3},
             "attention": {"bound": "hbm", "achieved": attn_b / attn_t / 1e9 if attn_t else 0.0, "peak": PEAK_HBM_GBS,
                           "unit": "GB/s", "frac": (attn_b / attn_t / 1e9 / PEAK_HBM_GBS) if attn_t else 0.0,
-                          "ms_per_step": attn_t * 1e3, "launches_per_step": sum(a[0] for a in attn.values())},
+                          "ms_per_step": attn_t * 1e3, "launches_per_step": sum(a[0] for a in attn.values()),
+                          "peak_measured": measured_hbm_copy_gbs()},
         }
         if args.detail:
             for k, d in sorted(detail.items(), key=lambda kv: -kv[1][3]):

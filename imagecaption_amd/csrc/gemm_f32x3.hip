@@ -17,9 +17,10 @@
 // the MFMAs of the other workgroups resident on the CU (2 at 128x128, 3 at 128x64, 4 at 64x64).
 // (A first version with four dedicated producer waves feeding four consumer waves was 5-25 % slower
 // at every shape: one MFMA-issuing wave per SIMD cannot hide its own LDS read latency.)
-// What bounds it (PMC, vocab projection, 128x128): 5.7 vector instructions per MFMA -- the split is
-// redone by every workgroup that touches an element -- against the ~6 that fit in an MFMA's shadow,
-// so the matrix pipe is busy 41 % of the time: 150-165 TFLOP/s fp32-equivalent on large products.
+// Where it stands (PMC, vocab projection, 128x128): matrix pipe busy 46 %, LDS 34 %, 5.7 vector
+// instructions per MFMA (~50 % of vector issue): nothing saturated, the two waves per SIMD expose their
+// LDS-read waits and store phases.  150-170 TFLOP/s fp32-equivalent on large products.  A variant that
+// split each operand once into bf16 planes in HBM (no split instructions in the GEMM) was NOT faster.
 // LDS images, three bf16 planes per operand:
 //   k-contiguous operand  : [row][40]   (80-B rows)  -> fragment = one ds_read_b128, conflict-free
 //   row-contiguous operand: [k][rows+32] (rows*2+64 B per k) -> written as loaded (no register

@@ -299,9 +299,9 @@ def main():
 
     # the instrumented step contains the gradient all-reduce: every rank must run it
     agg, detail = profile_step(trainer, feats, ids)
-    # the same step in the two optional arithmetic modes (never the headline `value`)
+    # the same step in the two optional arithmetic modes (never the headline `value`; N = 1 only, like cpu_baseline)
     modes = {}
-    if args.dtype == "fp32" and not args.no_modes:
+    if args.dtype == "fp32" and not args.no_modes and world == 1:
         for mode in ("f32x3", "bf16"):
             torch.manual_seed(42)
             m2 = ImageCaptioningModel(cfg["vocab"], cfg["d"], cfg["heads"], cfg["layers"], feature_dim=cfg["din"]).to(dev)

@@ -250,7 +250,8 @@ def main():
                     help="fp32 = reference precision (the headline); bf16 = bf16 MFMA products, fp32 elsewhere")
     ap.add_argument("--no-decode", action="store_true")
     ap.add_argument("--no-side-streams", action="store_true", help="single-stream step (diagnostic)")
-    ap.add_argument("--decode-images", type=int, default=4096, help="images per GPU for the decode leg")
+    ap.add_argument("--decode-images", type=int, default=12500,
+                    help="images per GPU for the decode leg (BASELINE configs[4]: 100k images over 8 GPUs)")
     ap.add_argument("--detail", action="store_true", help="print the per-shape kernel table to stderr")
     ap.add_argument("--no-modes", action="store_true", help="skip the f32x3 / bf16 legs of the default fp32 run")
     args = ap.parse_args()

@@ -278,9 +278,14 @@ GemmPlan plan_gemm_bf16(int M, int N, int K) {
     // want 128x128 tiles and enough K slices for >= 1024 workgroups.
     int bm = 64, split = 1;
     if (K >= 4096) {
-        bm = 128;
-        const long tiles = (long)cdiv(M, 128) * cdiv(N, 128);
-        while (tiles * split < 1024 && K / (split * 2) >= 512 && split < 32) split *= 2;
+        const long t128 = (long)cdiv(M, 128) * cdiv(N, 128);
+        if (t128 >= 64) {
+            bm = 128;
+            while (t128 * split < 1024 && K / (split * 2) >= 512 && split < 32) split *= 2;
+        } else {  // small outputs (512x512, 1536x512 weight gradients): 64x64 tiles, K cut down to 256-deep slices
+            const long t64 = (long)cdiv(M, 64) * cdiv(N, 64);
+            while (t64 * split < 768 && K / (split * 2) >= 256 && split < 32) split *= 2;
+        }
     } else {
         const long tiles = (long)cdiv(M, 64) * cdiv(N, 64);
         while (tiles * split < 256 && K / (split * 2) >= 256 && split < 16) split *= 2;

@@ -115,3 +115,34 @@ def test_decode_edge_shapes():
     assert torch.equal(got.cpu(), ids) and relerr(gsc, sc) < 1e-5
     with pytest.raises(RuntimeError):
         dec.beam(feats.to(DEV), beam=9, max_len=3)
+
+
+def test_one_trainer_over_changing_batch_shapes_tracks_the_oracle_optimizer():
+    """An epoch's last batch is smaller, and callers may change T: ONE CaptionTrainer (persistent logits
+    buffer, workspaces, side lane, flat optimizer state) steps through different (B, T, S-kind) batches and
+    must stay on the trajectory of the oracle model trained with torch.optim.AdamW + clip_grad_norm_
+    (ref train.py:24-61, main.py:95) on the same batches."""
+    from imagecaption_amd.trainer import CaptionTrainer
+    from oracle.torch_oracle import label_smoothed_loss
+    ref, model = pair(seed=3)          # ref stays in eval(): every dropout off (incl. MultiheadAttention's), grads still flow
+    opt = torch.optim.AdamW(ref.parameters(), lr=1e-3, weight_decay=0.01)
+    tr = CaptionTrainer(model, lr=1e-3, weight_decay=0.01, max_norm=1.0, dropout=0.0)
+    g = torch.Generator().manual_seed(9)
+    for B, T in [(5, 31), (3, 12), (5, 31), (1, 40), (8, 7)]:
+        feats = torch.randn(B, 5, 24, generator=g)
+        caps = torch.randint(5, 50, (B, T + 1), generator=g)
+        caps[:, 0] = 1
+        loss_ref = label_smoothed_loss(ref(feats, caps[:, :-1]), caps[:, 1:])
+        opt.zero_grad()
+        loss_ref.backward()
+        torch.nn.utils.clip_grad_norm_(ref.parameters(), 1.0)
+        opt.step()
+        loss = tr.step(feats.to(DEV), caps.to(DEV))
+        assert abs(loss.item() - loss_ref.item()) < 5e-5 * abs(loss_ref.item()), (B, T)
+    # Parameters whose true gradient is zero (the key bias: softmax is shift-invariant) receive rounding noise that
+    # Adam normalises to +-lr per step on both sides independently, so a few elements may differ by up to steps * lr.
+    pref = dict(ref.named_parameters())
+    for n, p in model.named_parameters():
+        diff = (p.detach().cpu() - pref[n].detach()).abs()
+        assert float((diff < 2e-5).float().mean()) > (0.6 if "in_proj_bias" in n else 0.995), n
+        assert float(diff.max()) < 5 * 1.2e-3, n

@@ -146,3 +146,25 @@ def test_one_trainer_over_changing_batch_shapes_tracks_the_oracle_optimizer():
         diff = (p.detach().cpu() - pref[n].detach()).abs()
         assert float((diff < 2e-5).float().mean()) > (0.6 if "in_proj_bias" in n else 0.995), n
         assert float(diff.max()) < 5 * 1.2e-3, n
+
+
+def test_device_prefetcher_yields_the_loader_batches_in_order_and_feeds_the_trainer():
+    from imagecaption_amd.data import DevicePrefetcher
+    from imagecaption_amd.trainer import CaptionTrainer
+    g = torch.Generator().manual_seed(4)
+    batches = [(torch.randn(B, 5, 24, generator=g), torch.randint(5, 50, (B, 13), generator=g)) for B in (6, 6, 6, 2)]
+    for _, c in batches:
+        c[:, 0] = 1
+    seen = list(DevicePrefetcher(batches, DEV, depth=2))
+    assert len(seen) == len(batches)
+    for (f, c), (df, dc) in zip(batches, seen):
+        assert df.device.type == "cuda" and torch.equal(df.cpu(), f) and torch.equal(dc.cpu(), c)
+    _, model = pair(seed=8)
+    tr_a = CaptionTrainer(model, dropout=0.0)
+    la = [tr_a.step(f, c).item() for f, c in DevicePrefetcher(batches, DEV)]
+    _, model_b = pair(seed=8)
+    tr_b = CaptionTrainer(model_b, dropout=0.0)
+    lb = [tr_b.step(f.to(DEV), c.to(DEV)).item() for f, c in batches]
+    assert la == lb                                               # bitwise: same kernels, same data
+    with pytest.raises(ValueError):
+        DevicePrefetcher(batches, "cpu")

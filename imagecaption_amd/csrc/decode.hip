@@ -458,23 +458,10 @@ extern "C" int capdec_beam_select(const void* logits, int ldl, const void* score
     CAPDEC_REQUIRE(N > 0 && W >= 1 && W <= MAXW && V >= W + 1 && ldl >= V && t >= 0 && t < Tmax,
                    "capdec_beam_select: bad shape N=%d W=%d (max %d) V=%d t=%d Tmax=%d", N, W, MAXW, V, t, Tmax);
     CAPDEC_REQUIRE((uint64_t)W * V < (1ull << 31), "capdec_beam_select: W*V too large");
-    // rows that can be staged in LDS (float4-readable, at most 144 KB) take the one-read kernel
+    // rows that can be staged in LDS (float4-readable, at most 60 KB: two or more workgroups per CU and no opt-in
+    // for large dynamic LDS needed) take the one-read kernel
     const size_t lds = (size_t)V * sizeof(float);
-    bool stage = V % 4 == 0 && ldl % 4 == 0 && aligned16(logits) && lds <= 144 * 1024;
-    if (stage && lds > 48 * 1024) {
-        static bool configured[64] = {};
-        int dev = 0;
-        if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) return CAPDEC_ERR_LAUNCH;
-        if (!configured[dev]) {
-            const void* fns[4] = {reinterpret_cast<const void*>(&beam_select_kernel<true, 2>),
-                                  reinterpret_cast<const void*>(&beam_select_kernel<true, 4>),
-                                  reinterpret_cast<const void*>(&beam_select_kernel<true, 6>),
-                                  reinterpret_cast<const void*>(&beam_select_kernel<true, MAXW + 1>)};
-            for (const void* fn : fns)
-                if (hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, 144 * 1024) != hipSuccess) stage = false;
-            configured[dev] = stage;
-        }
-    }
+    const bool stage = V % 4 == 0 && ldl % 4 == 0 && aligned16(logits) && lds <= 60 * 1024;
 #define CAPDEC_BEAM(ST, LW) \
     hipLaunchKernelGGL((beam_select_kernel<ST, LW>), dim3(N), dim3(256), ST ? lds : 0, (hipStream_t)stream, \
                        (const float*)logits, ldl, (const float*)score_in, (float*)score_out, fin_in, fin_out, anc_in, \

@@ -57,8 +57,10 @@ S_EMBED, S_PROJ, S_HEAD = 1000, 1001, 1002
 # ---------------------------------------------------------------------------------------------
 # decoder layer
 # ---------------------------------------------------------------------------------------------
-def layer_fwd(P, x, mem, B, T, S, H, causal, dp, l, save):
-    """x [B*T,d], mem [B*S,d] -> [B*T,d].  ``save`` (dict or None) receives what backward needs."""
+def layer_fwd(P, x, mem, B, T, S, H, causal, dp, l, save, kv=None):
+    """x [B*T,d], mem [B*S,d] -> [B*T,d].  ``save`` (dict or None) receives what backward needs.
+    ``kv``: this layer's cross-attention K/V projection of ``mem`` when the caller has already computed it
+    (stack_fwd batches all layers' projections into one GEMM); a [B*S, 2d] row-strided view."""
     d = x.shape[1]
     p, sid = dp.p, 16 * l
     qkv = ops.linear_fwd(x, P["self_attn.in_proj_weight"], P["self_attn.in_proj_bias"])
@@ -71,7 +73,8 @@ def layer_fwd(P, x, mem, B, T, S, H, causal, dp, l, save):
     # S == 1 (ref models.py:104): softmax over one key is 1 whatever the query, so the query projection
     # cannot reach the output and its gradient is exactly zero -- it is skipped (x1 stands in as q)
     q = x1 if S == 1 else ops.linear_fwd(x1, wc[:d], bc[:d])
-    kv = ops.linear_fwd(mem, wc[d:], bc[d:])
+    if kv is None:
+        kv = ops.linear_fwd(mem, wc[d:], bc[d:])
     c, lse2 = ops.attn_fwd(q, kv[:, :d], kv[:, d:], B, H, T, S, False, p, dp.seed(sid + S_CA_P),
                            save_lse=save is not None and S != 1)
     s2 = ops.linear_fwd(c, P["multihead_attn.out_proj.weight"], P["multihead_attn.out_proj.bias"], drop_p=p,
@@ -89,8 +92,10 @@ def layer_fwd(P, x, mem, B, T, S, H, causal, dp, l, save):
     return x3
 
 
-def layer_bwd(P, G, sv, dx3, mem, dmem, B, T, S, H, causal, dp, l):
-    """Backward of layer_fwd.  Writes parameter grads into G[...] (overwrite); returns (dx, dmem)."""
+def layer_bwd(P, G, sv, dx3, mem, dmem, B, T, S, H, causal, dp, l, dkv=None):
+    """Backward of layer_fwd.  Writes parameter grads into G[...] (overwrite); returns (dx, dmem).
+    ``dkv``: a [B*S, 2d] row-strided view to receive dK | dV when the caller batches the d(memory) product
+    over all layers (stack_bwd); then ``dmem`` is passed through untouched."""
     d = dx3.shape[1]
     p, sid = dp.p, 16 * l
     tr = p > 0.0
@@ -109,7 +114,9 @@ def layer_bwd(P, G, sv, dx3, mem, dmem, B, T, S, H, causal, dp, l):
     ops.linear_wgrad(g2m, sv["c"], dw=G["multihead_attn.out_proj.weight"], db=G["multihead_attn.out_proj.bias"])
     dc = ops.linear_dgrad(g2m, P["multihead_attn.out_proj.weight"])
     kv = sv["kv"]
-    dkv = torch.empty_like(kv)
+    batched = dkv is not None
+    if not batched:
+        dkv = torch.empty_like(kv)
     dq, _, _ = ops.attn_bwd(sv["q"], kv[:, :d], kv[:, d:], sv["c"], dc, sv["lse2"], B, H, T, S, False, p,
                             dp.seed(sid + S_CA_P), dk=dkv[:, :d], dv=dkv[:, d:], need_dq=S != 1)
     wc = P["multihead_attn.in_proj_weight"]
@@ -120,7 +127,8 @@ def layer_bwd(P, G, sv, dx3, mem, dmem, B, T, S, H, causal, dp, l):
     else:
         ops.linear_wgrad(dq, sv["x1"], dw=gw[:d], db=gb[:d])
     ops.linear_wgrad(dkv, mem, dw=gw[d:], db=gb[d:])
-    dmem = ops.linear_dgrad(dkv, wc[d:], addend=dmem)
+    if not batched:
+        dmem = ops.linear_dgrad(dkv, wc[d:], addend=dmem)
     dx1 = g2 if S == 1 else ops.linear_dgrad(dq, wc[:d], addend=g2)
     g1, g1m, _, _ = ops.layernorm_bwd(dx1, sv["s1"], P["norm1.weight"], P["norm1.bias"], sv["mean1"], sv["rstd1"],
                                       drop2_p=p, seed2=dp.seed(sid + S_SA_OUT), want_dx_drop=tr,
@@ -142,14 +150,24 @@ def layer_bwd(P, G, sv, dx3, mem, dmem, B, T, S, H, causal, dp, l):
 # ---------------------------------------------------------------------------------------------
 def stack_fwd(layers, norm_w, norm_b, x, mem, B, T, S, H, causal, dp, save):
     saves = [] if save is not None else None
+    # The cross-attention K/V projections of all layers depend only on the memory: one GEMM with the layers'
+    # weights stacked ([L*2d, d], a 6 MB gather at C2) instead of L mid-size ones; each layer reads its
+    # [B*S, 2d] column block in place (the attention kernels take row strides).
+    d = x.shape[1]
+    kv_all = w_all = None
+    if len(layers) > 1 and mem.shape[0] >= 1024:
+        w_all = torch.cat([P["multihead_attn.in_proj_weight"][d:] for P in layers])
+        b_all = torch.cat([P["multihead_attn.in_proj_bias"][d:] for P in layers])
+        kv_all = ops.linear_fwd(mem, w_all, b_all)
     for l, P in enumerate(layers):
         sv = {} if save is not None else None
-        x = layer_fwd(P, x, mem, B, T, S, H, causal, dp, l, sv)
+        x = layer_fwd(P, x, mem, B, T, S, H, causal, dp, l, sv,
+                      kv=None if kv_all is None else kv_all[:, l * 2 * d:(l + 1) * 2 * d])
         if saves is not None:
             saves.append(sv)
     y, mean, rstd = ops.layernorm_fwd(x, norm_w, norm_b, save_stats=save is not None)
     if save is not None:
-        save.update(layers=saves, xl=x, mean=mean, rstd=rstd)
+        save.update(layers=saves, xl=x, mean=mean, rstd=rstd, w_kv_all=w_all if kv_all is not None else None)
     return y
 
 
@@ -159,10 +177,19 @@ def stack_bwd(layers, grads, norm_w, norm_b, g_norm_w, g_norm_b, sv, dy, mem, B,
     dx, _, _, _ = ops.layernorm_bwd(dy, sv["xl"], norm_w, norm_b, sv["mean"], sv["rstd"], dgamma=g_norm_w,
                                     dbeta=g_norm_b)
     dmem = None
+    # forward batched the cross K/V projections: d(memory) = [dKV_0 | ... | dKV_L-1] @ [W_0; ...; W_L-1] is then
+    # ONE product over K = L*2d after the last layer instead of L accumulating ones (no parameter gradient is
+    # involved, so the bucket order of the data-parallel reducer is untouched)
+    w_all = sv.get("w_kv_all")
+    d = dy.shape[1]
+    dkv_all = torch.empty((mem.shape[0], w_all.shape[0]), dtype=torch.float32, device=dy.device) if w_all is not None else None
     for l in range(len(layers) - 1, -1, -1):
-        dx, dmem = layer_bwd(layers[l], grads[l], sv["layers"][l], dx, mem, dmem, B, T, S, H, causal, dp, l)
+        dx, dmem = layer_bwd(layers[l], grads[l], sv["layers"][l], dx, mem, dmem, B, T, S, H, causal, dp, l,
+                             dkv=None if dkv_all is None else dkv_all[:, l * 2 * d:(l + 1) * 2 * d])
         if after_layer is not None:
             after_layer(l)
+    if dkv_all is not None:
+        dmem = ops.linear_dgrad(dkv_all, w_all)
     return dx, dmem
 
 

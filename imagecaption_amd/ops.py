@@ -306,7 +306,7 @@ def embed_bwd(ids, dout, V, drop_p=0.0, seed=0, dE=None, planned_ws=None):
         check(l.capdec_embed_bwd_apply(ptr(ids), ptr(_req(dout, "embed_bwd.dout")), ptr(dE), B, T, d, V, float(drop_p),
                                        int(seed), ptr(planned_ws), planned_ws.numel(), stream()), "capdec_embed_bwd_apply")
         return dE
-    ws = _capi.workspace(l.capdec_embed_bwd_workspace_bytes(B, T, d, V), dout.device)
+    ws = _capi.workspace(l.capdec_embed_bwd_workspace_bytes(B, T, d, V), dout.device, _WS_TAG)
     check(l.capdec_embed_bwd(ptr(ids), ptr(_req(dout, "embed_bwd.dout")), ptr(dE), B, T, d, V, float(drop_p), int(seed),
                              ptr(ws), ws.numel(), stream()), "capdec_embed_bwd")
     return dE

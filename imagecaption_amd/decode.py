@@ -48,9 +48,14 @@ class CaptionDecoder:
         self.dp = engine.DropoutPlan(0.0)
 
     # ---- one decode step for R = N*W rows at position t ------------------------------------------
-    def _step(self, tok, t, st):
+    def _step(self, tok, t, st, collapse=False):
+        """``collapse`` (beam search, t = 0): every beam of an image is the same <START> hypothesis, so the step
+        runs for ONE row per image; its K/V land in the cache slot of beam 0 (the ancestry table the selection
+        writes points every beam there) and the caller replicates the logits.  The cache is then addressed as
+        N rows of W*Tmax positions."""
         m, d, H = self.model, self.d, self.H
-        R, W, S, Tmax = st["R"], st["W"], st["S"], st["Tmax"]
+        S = st["S"]
+        R, W, Tmax, every = (st["N"], 1, st["W"] * st["Tmax"], st["W"]) if collapse else (st["R"], st["W"], st["Tmax"], 1)
         dh = d // H
         scale = 1.0 / math.sqrt(dh)
         l = lib()
@@ -58,10 +63,10 @@ class CaptionDecoder:
         for li, P in enumerate(self.layers):
             w_in, b_in = P["self_attn.in_proj_weight"], P["self_attn.in_proj_bias"]
             q = ops.linear_fwd(x, w_in[:d], b_in[:d])
-            cache = st["cache"][li]  # [R, Tmax, 2d]
-            ops.linear_fwd(x, w_in[d:], b_in[d:], out=cache[:, t, :])  # scatter via the output row stride
+            cache = st["cache"][li]  # [N*W, Tmax, 2d]
+            ops.linear_fwd(x, w_in[d:], b_in[d:], out=cache[::every, t, :])  # scatter via the output row stride
             a = torch.empty((R, d), dtype=torch.float32, device=x.device)
-            c2 = cache.view(R * Tmax, 2 * d)
+            c2 = cache.view(-1, 2 * d)
             check(l.capdec_decode_attn(ptr(q), d, ptr(c2), ptr(c2[:, d:]), 2 * d, ptr(a), d, ptr(st["anc"][st["cur"]]),
                                        R, H, dh, Tmax, t, W, S, scale, stream()), "capdec_decode_attn")
             s1 = ops.linear_fwd(a, P["self_attn.out_proj.weight"], P["self_attn.out_proj.bias"], addend=x)
@@ -131,7 +136,10 @@ class CaptionDecoder:
         for t in range(max_len):
             st["cur"] = cur
             with ops.compute_dtype(self.dtype):
-                logits = self._step(tok, t, st)
+                if t == 0 and beam > 1:   # all beams of an image are the same hypothesis: one row per image
+                    logits = self._step(tok[::beam].contiguous(), 0, st, collapse=True).repeat_interleave(beam, dim=0)
+                else:
+                    logits = self._step(tok, t, st)
             nxt = cur ^ 1
             check(l.capdec_beam_select(ptr(logits), logits.stride(0), ptr(score[cur]), ptr(score[nxt]), ptr(fin[cur]),
                                        ptr(fin[nxt]), ptr(st["anc"][cur]), ptr(st["anc"][nxt]), ptr(st["seq"][cur]),

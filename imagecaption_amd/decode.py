@@ -72,12 +72,19 @@ class CaptionDecoder:
             s1 = ops.linear_fwd(a, P["self_attn.out_proj.weight"], P["self_attn.out_proj.bias"], addend=x)
             x1, _, _ = ops.layernorm_fwd(s1, P["norm1.weight"], P["norm1.bias"], save_stats=False)
             wc, bc = P["multihead_attn.in_proj_weight"], P["multihead_attn.in_proj_bias"]
-            q = x1 if S == 1 else ops.linear_fwd(x1, wc[:d], bc[:d])  # one key: the query cannot matter
-            kv = st["cross_kv"][li]  # [N*S, 2d]
-            c = torch.empty((R, d), dtype=torch.float32, device=x.device)
-            check(l.capdec_decode_attn(ptr(q), d, ptr(kv), ptr(kv[:, d:]), 2 * d, ptr(c), d, None, R, H, dh, Tmax, t, W,
-                                       S, scale, stream()), "capdec_decode_attn")
-            s2 = ops.linear_fwd(c, P["multihead_attn.out_proj.weight"], P["multihead_attn.out_proj.bias"], addend=x1)
+            if S == 1:
+                # one key (ref models.py:104): the context is that key's value whatever the query, so the whole
+                # cross-attention branch out_proj(v) + bias is a per-image constant, computed once in _prepare;
+                # (acc + bias) + x1 rounds exactly like the fused GEMM epilogue does
+                u = st["cross_out"][li]
+                s2 = (u if W == 1 else u.repeat_interleave(W, dim=0)) + x1
+            else:
+                q = ops.linear_fwd(x1, wc[:d], bc[:d])
+                kv = st["cross_kv"][li]  # [N*S, 2d]
+                c = torch.empty((R, d), dtype=torch.float32, device=x.device)
+                check(l.capdec_decode_attn(ptr(q), d, ptr(kv), ptr(kv[:, d:]), 2 * d, ptr(c), d, None, R, H, dh, Tmax, t,
+                                           W, S, scale, stream()), "capdec_decode_attn")
+                s2 = ops.linear_fwd(c, P["multihead_attn.out_proj.weight"], P["multihead_attn.out_proj.bias"], addend=x1)
             x2, _, _ = ops.layernorm_fwd(s2, P["norm2.weight"], P["norm2.bias"], save_stats=False)
             h = ops.linear_fwd(x2, P["linear1.weight"], P["linear1.bias"], act=ACT_GELU)
             s3 = ops.linear_fwd(h, P["linear2.weight"], P["linear2.bias"], addend=x2)
@@ -90,14 +97,21 @@ class CaptionDecoder:
         dev = features.device
         N = features.shape[0]
         S = 1 if features.dim() == 2 else features.shape[1]
-        cross = []
+        cross, cross_out = [], []
         with ops.compute_dtype(self.dtype):
             mem = engine.proj_fwd(self.proj, features.reshape(N * S, -1), self.dp, None)  # [N*S, d]
             for P in self.layers:
                 wc, bc = P["multihead_attn.in_proj_weight"], P["multihead_attn.in_proj_bias"]
-                cross.append(ops.linear_fwd(mem, wc[d:], bc[d:]))
+                if S == 1:  # only V is ever used; the branch's output is constant per image
+                    v = ops.linear_fwd(mem, wc[2 * d:], bc[2 * d:])
+                    cross.append(None)
+                    cross_out.append(ops.linear_fwd(v, P["multihead_attn.out_proj.weight"],
+                                                    P["multihead_attn.out_proj.bias"]))
+                else:
+                    cross.append(ops.linear_fwd(mem, wc[d:], bc[d:]))
+                    cross_out.append(None)
         R = N * W
-        st = dict(N=N, W=W, R=R, S=S, Tmax=Tmax, cross_kv=cross, cur=0,
+        st = dict(N=N, W=W, R=R, S=S, Tmax=Tmax, cross_kv=cross, cross_out=cross_out, cur=0,
                   cache=[torch.empty((R, Tmax, 2 * d), dtype=torch.float32, device=dev) for _ in self.layers],
                   anc=[torch.arange(R, dtype=torch.int32, device=dev).view(R, 1).repeat(1, Tmax).contiguous()
                        for _ in range(2)],

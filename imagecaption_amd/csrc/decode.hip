@@ -176,19 +176,21 @@ __global__ __launch_bounds__(256) void greedy_select_kernel(const float* __restr
     __shared__ Cand sh[4];
     const int r = blockIdx.x;
     const float* z = logits + (size_t)r * ldl;
-    Cand c{-INFINITY, 0x7fffffff};
+    // one pass: per-thread best and second best, then two block-wide tournaments (the second one gives
+    // the runner-up for the recorded top-1/top-2 margin)
+    Cand c{-INFINITY, 0x7fffffff}, c2{-INFINITY, 0x7fffffff};
     for (int v = threadIdx.x; v < V; v += 256) {
-        Cand d{z[v], v};
-        if (better(d, c)) c = d;
+        const Cand d{z[v], v};
+        if (better(d, c)) {
+            c2 = c;
+            c = d;
+        } else if (better(d, c2)) {
+            c2 = d;
+        }
     }
     const Cand b = block_best(c, sh);
-    // runner-up (for the recorded top-1/top-2 margin)
-    Cand c2{-INFINITY, 0x7fffffff};
-    for (int v = threadIdx.x; v < V; v += 256) {
-        Cand d{z[v], v};
-        if (v != b.i && better(d, c2)) c2 = d;
-    }
-    const Cand b2 = block_best(c2, sh);
+    __syncthreads();
+    const Cand b2 = block_best(c.i == b.i ? c2 : c, sh);
     if (threadIdx.x == 0) {
         const int was_done = done[r];
         const int tok = was_done ? TOK_PAD : b.i;
@@ -354,19 +356,34 @@ __global__ __launch_bounds__(256) void sample_select_kernel(SampleParams p) {
             }
             return l;
         };
+        // one pass: every thread keeps the best SAMPLE_K of its share (score desc, id asc -- a strict total
+        // order, so the result does not depend on which thread sees which element), then SAMPLE_K block-wide
+        // tournaments pop the winners.  -inf candidates stay eligible (ties -> lowest id).
+        Cand loc[SAMPLE_K];
+#pragma unroll
+        for (int k = 0; k < SAMPLE_K; ++k) loc[k] = Cand{-INFINITY, 0x7fffffff};
+        auto offer = [&](int v) {
+            const Cand c{biased(v), v};
+            if (better(c, loc[SAMPLE_K - 1])) {
+                loc[SAMPLE_K - 1] = c;
+#pragma unroll
+                for (int k = SAMPLE_K - 1; k > 0; --k)
+                    if (better(loc[k], loc[k - 1])) {
+                        const Cand tmp = loc[k]; loc[k] = loc[k - 1]; loc[k - 1] = tmp;
+                    }
+            }
+        };
+        for (int v = tid; v < p.V; v += 256) offer(v);
         Cand top[SAMPLE_K];
 #pragma unroll
         for (int k = 0; k < SAMPLE_K; ++k) {
-            Cand c{-INFINITY, 0x7fffffff};
-            for (int v = tid; v < p.V; v += 256) {
-                bool taken = false;
+            const Cand b = block_best(loc[0], sh);
+            if (loc[0].i == b.i) {
 #pragma unroll
-                for (int q = 0; q < SAMPLE_K; ++q) taken |= (q < k) && (top[q].i == v);
-                if (taken) continue;
-                const Cand d{biased(v), v};  // -inf candidates stay eligible (ties -> lowest id)
-                if (better(d, c)) c = d;
+                for (int q = 0; q < SAMPLE_K - 1; ++q) loc[q] = loc[q + 1];
+                loc[SAMPLE_K - 1] = Cand{-INFINITY, 0x7fffffff};
             }
-            top[k] = block_best(c, sh);
+            top[k] = b;
             __syncthreads();
         }
         // weights exp(l - l_top) stand in for the top-5 probabilities (the softmax normaliser cancels)

@@ -166,7 +166,9 @@ int capdec_adamw(void* p, const void* g, void* m, void* v, size_t n, float lr, f
  *   - self (anc != NULL): keys j = 0..t of the cache; position j of row r lives in cache row
  *     (slot*Tmax + j), slot = (j == t ? r : anc[r*Tmax + j]); k / v point at the K and V halves of the
  *     cache, row stride ldkv;
- *   - cross (anc == NULL): keys j = 0..S-1 of image r / W: row ((r/W)*S + j) of k / v.
+ *   - cross (anc == NULL): keys j = 0..S-1 of image r / W: row ((r/W)*S + j) of k / v.  With W > 1 (and R a
+ *     multiple of W) the W beams of an image are served by one wave that reads the image's K / V once; a
+ *     row's result has the same bits whatever W is.
  * capdec_greedy_select: seq[r, t] = next_tok[r] = done[r] ? PAD : argmax_v logits[r, v] (ties -> lowest id);
  *   done[r] |= (token == END); gap[r] = min(gap[r], top1 - top2) on live rows (gap may be NULL).
  * capdec_beam_select (the beam top-k / reorder kernel), per image n with W <= 8 beams: rank the W*V

@@ -57,6 +57,21 @@ S_EMBED, S_PROJ, S_HEAD = 1000, 1001, 1002
 # ---------------------------------------------------------------------------------------------
 # decoder layer
 # ---------------------------------------------------------------------------------------------
+_EYES = {}
+
+
+def _eye(H, device):
+    key = (H, device)
+    if key not in _EYES:
+        _EYES[key] = torch.eye(H, dtype=torch.float32, device=device)
+    return _EYES[key]
+
+
+def _single_key_fast(S, d, H):
+    """The streaming single-key cross-attention branch (capdec_cross1_*) covers d % 64 == 0 and power-of-two heads."""
+    return S == 1 and d % 64 == 0 and H in (1, 2, 4, 8, 16)
+
+
 def layer_fwd(P, x, mem, B, T, S, H, causal, dp, l, save, kv=None):
     """x [B*T,d], mem [B*S,d] -> [B*T,d].  ``save`` (dict or None) receives what backward needs.
     ``kv``: this layer's cross-attention K/V projection of ``mem`` when the caller has already computed it
@@ -70,15 +85,24 @@ def layer_fwd(P, x, mem, B, T, S, H, causal, dp, l, save, kv=None):
                         seed=dp.seed(sid + S_SA_OUT), addend=x)
     x1, mean1, rstd1 = ops.layernorm_fwd(s1, P["norm1.weight"], P["norm1.bias"], save_stats=save is not None)
     wc, bc = P["multihead_attn.in_proj_weight"], P["multihead_attn.in_proj_bias"]
-    # S == 1 (ref models.py:104): softmax over one key is 1 whatever the query, so the query projection
-    # cannot reach the output and its gradient is exactly zero -- it is skipped (x1 stands in as q)
-    q = x1 if S == 1 else ops.linear_fwd(x1, wc[:d], bc[:d])
     if kv is None:
         kv = ops.linear_fwd(mem, wc[d:], bc[d:])
-    c, lse2 = ops.attn_fwd(q, kv[:, :d], kv[:, d:], B, H, T, S, False, p, dp.seed(sid + S_CA_P),
-                           save_lse=save is not None and S != 1)
-    s2 = ops.linear_fwd(c, P["multihead_attn.out_proj.weight"], P["multihead_attn.out_proj.bias"], drop_p=p,
-                        seed=dp.seed(sid + S_CA_OUT), addend=x1)
+    q = c = lse2 = vblk = None
+    if _single_key_fast(S, d, H):
+        # ONE memory position (ref models.py:104): softmax over one key is 1 whatever the query (the query
+        # projection cannot reach the output, its gradient is exactly zero) and head h's context is v[b, h-slice]
+        # for every token, kept or dropped by the probability dropout.  The out-projection therefore runs on
+        # B*H rows (v masked to one head per row) and a streaming kernel assembles the [B*T, d] branch output.
+        vblk = (kv[:, d:].reshape(B, 1, H, d // H) * _eye(H, x.device).view(1, H, H, 1)).reshape(B * H, d)
+        U = ops.linear_fwd(vblk, P["multihead_attn.out_proj.weight"])
+        s2 = ops.cross1_fwd(U, P["multihead_attn.out_proj.bias"], x1, B, T, H, p, dp.seed(sid + S_CA_P), p,
+                            dp.seed(sid + S_CA_OUT))
+    else:
+        q = x1 if S == 1 else ops.linear_fwd(x1, wc[:d], bc[:d])  # S == 1 with an odd geometry: generic kernels
+        c, lse2 = ops.attn_fwd(q, kv[:, :d], kv[:, d:], B, H, T, S, False, p, dp.seed(sid + S_CA_P),
+                               save_lse=save is not None and S != 1)
+        s2 = ops.linear_fwd(c, P["multihead_attn.out_proj.weight"], P["multihead_attn.out_proj.bias"], drop_p=p,
+                            seed=dp.seed(sid + S_CA_OUT), addend=x1)
     x2, mean2, rstd2 = ops.layernorm_fwd(s2, P["norm2.weight"], P["norm2.bias"], save_stats=save is not None)
     u = torch.empty((x.shape[0], P["linear1.weight"].shape[0]), dtype=torch.float32, device=x.device) \
         if save is not None else None
@@ -87,7 +111,7 @@ def layer_fwd(P, x, mem, B, T, S, H, causal, dp, l, save, kv=None):
     s3 = ops.linear_fwd(h, P["linear2.weight"], P["linear2.bias"], drop_p=p, seed=dp.seed(sid + S_FFN_OUT), addend=x2)
     x3, mean3, rstd3 = ops.layernorm_fwd(s3, P["norm3.weight"], P["norm3.bias"], save_stats=save is not None)
     if save is not None:
-        save.update(x=x, qkv=qkv, a=a, lse1=lse1, s1=s1, mean1=mean1, rstd1=rstd1, x1=x1, q=q, kv=kv, c=c, lse2=lse2,
+        save.update(x=x, qkv=qkv, a=a, lse1=lse1, s1=s1, mean1=mean1, rstd1=rstd1, x1=x1, q=q, kv=kv, c=c, lse2=lse2, vblk=vblk,
                     s2=s2, mean2=mean2, rstd2=rstd2, x2=x2, u=u, h=h, s3=s3, mean3=mean3, rstd3=rstd3)
     return x3
 
@@ -111,21 +135,34 @@ def layer_bwd(P, G, sv, dx3, mem, dmem, B, T, S, H, causal, dp, l, dkv=None):
                                       drop2_p=p, seed2=dp.seed(sid + S_CA_OUT), want_dx_drop=tr,
                                       dgamma=G["norm2.weight"], dbeta=G["norm2.bias"])
     g2m = g2m if tr else g2
-    ops.linear_wgrad(g2m, sv["c"], dw=G["multihead_attn.out_proj.weight"], db=G["multihead_attn.out_proj.bias"])
-    dc = ops.linear_dgrad(g2m, P["multihead_attn.out_proj.weight"])
     kv = sv["kv"]
     batched = dkv is not None
-    if not batched:
-        dkv = torch.empty_like(kv)
-    dq, _, _ = ops.attn_bwd(sv["q"], kv[:, :d], kv[:, d:], sv["c"], dc, sv["lse2"], B, H, T, S, False, p,
-                            dp.seed(sid + S_CA_P), dk=dkv[:, :d], dv=dkv[:, d:], need_dq=S != 1)
     wc = P["multihead_attn.in_proj_weight"]
     gw, gb = G["multihead_attn.in_proj_weight"], G["multihead_attn.in_proj_bias"]
-    if S == 1:  # dq == 0 exactly: zero query-projection gradients, nothing flows to x1 through q
-        gw[:d].zero_()
+    if _single_key_fast(S, d, H):  # see layer_fwd: everything of the branch lives on B*H rows
+        dU, dbp = ops.cross1_bwd(g2m, B, T, H, p, dp.seed(sid + S_CA_P))
+        ops.linear_wgrad(dU, sv["vblk"], dw=G["multihead_attn.out_proj.weight"])
+        torch.sum(dbp, dim=0, out=G["multihead_attn.out_proj.bias"])
+        dvblk = ops.linear_dgrad(dU, P["multihead_attn.out_proj.weight"])  # [B*H, d]; head h's slice of row (b, h) is dv
+        dv = torch.diagonal(dvblk.view(B, H, H, d // H), dim1=1, dim2=2).permute(0, 2, 1).reshape(B, d)
+        if not batched:
+            dkv = torch.empty_like(kv)
+        dkv[:, :d].zero_()      # dk == 0 exactly (p = 1 for the only key), as torch computes it
+        dkv[:, d:].copy_(dv)
+        gw[:d].zero_()          # dq == 0 exactly: zero query-projection gradients, nothing flows to x1 through q
         gb[:d].zero_()
     else:
-        ops.linear_wgrad(dq, sv["x1"], dw=gw[:d], db=gb[:d])
+        ops.linear_wgrad(g2m, sv["c"], dw=G["multihead_attn.out_proj.weight"], db=G["multihead_attn.out_proj.bias"])
+        dc = ops.linear_dgrad(g2m, P["multihead_attn.out_proj.weight"])
+        if not batched:
+            dkv = torch.empty_like(kv)
+        dq, _, _ = ops.attn_bwd(sv["q"], kv[:, :d], kv[:, d:], sv["c"], dc, sv["lse2"], B, H, T, S, False, p,
+                                dp.seed(sid + S_CA_P), dk=dkv[:, :d], dv=dkv[:, d:], need_dq=S != 1)
+        if S == 1:
+            gw[:d].zero_()
+            gb[:d].zero_()
+        else:
+            ops.linear_wgrad(dq, sv["x1"], dw=gw[:d], db=gb[:d])
     ops.linear_wgrad(dkv, mem, dw=gw[d:], db=gb[d:])
     if not batched:
         dmem = ops.linear_dgrad(dkv, wc[d:], addend=dmem)

@@ -312,6 +312,35 @@ def embed_bwd(ids, dout, V, drop_p=0.0, seed=0, dE=None, planned_ws=None):
     return dE
 
 
+def cross1_fwd(U, bias, addend, B, T, H, attn_p=0.0, attn_seed=0, out_p=0.0, out_seed=0):
+    """Cross-attention branch over ONE memory position: addend + dropout_out(bias + sum_h keep_h/(1-p) U[b,h,:]);
+    U [B*H, d] = per-image, per-head out-projected values, addend [B*T, d].  See capdec_cross1_fwd."""
+    for t, n in ((U, "cross1.U"), (addend, "cross1.addend")):
+        if not _mat(t, n).is_contiguous():
+            raise _capi.CapdecError(f"{n}: must be contiguous")
+    d = U.shape[1]
+    if U.shape[0] != B * H or tuple(addend.shape) != (B * T, d) or _req(bias, "cross1.bias").numel() != d:
+        raise _capi.CapdecError(f"cross1_fwd: shapes U {tuple(U.shape)} bias {tuple(bias.shape)} addend {tuple(addend.shape)} "
+                                f"do not match B={B} T={T} H={H}")
+    out = torch.empty_like(addend)
+    check(lib().capdec_cross1_fwd(ptr(U), ptr(bias), ptr(addend), ptr(out), B, T, H, d, float(attn_p),
+                                  int(attn_seed) & 0xFFFFFFFFFFFFFFFF, float(out_p), int(out_seed) & 0xFFFFFFFFFFFFFFFF,
+                                  stream()), "capdec_cross1_fwd")
+    return out
+
+
+def cross1_bwd(g, B, T, H, attn_p=0.0, attn_seed=0):
+    """(dU [B*H, d], dbias_part [B, d]) from g [B*T, d], the gradient at the branch output (output dropout applied)."""
+    if not _mat(g, "cross1.g").is_contiguous() or g.shape[0] != B * T:
+        raise _capi.CapdecError(f"cross1_bwd: g {tuple(g.shape)} must be a contiguous [B*T, d] with B={B} T={T}")
+    d = g.shape[1]
+    dU = torch.empty((B * H, d), dtype=torch.float32, device=g.device)
+    dbp = torch.empty((B, d), dtype=torch.float32, device=g.device)
+    check(lib().capdec_cross1_bwd(ptr(g), ptr(dU), ptr(dbp), B, T, H, d, float(attn_p), int(attn_seed) & 0xFFFFFFFFFFFFFFFF,
+                                  stream()), "capdec_cross1_bwd")
+    return dU, dbp
+
+
 def attn_fwd(q, k, v, B, H, Tq, Tk, causal, drop_p=0.0, seed=0, out=None, save_lse=True):
     """q [B*Tq, >=H*dh] / k, v [B*Tk, ...] row-strided 2-D views; returns o [B*Tq, H*dh], lse [B,H,Tq]."""
     _mat(q, "attn.q"), _mat(k, "attn.k"), _mat(v, "attn.v")

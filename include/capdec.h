@@ -160,6 +160,22 @@ int capdec_clip_scale(void* g, size_t n, const void* gnorm_sq, float max_norm, c
 int capdec_adamw(void* p, const void* g, void* m, void* v, size_t n, float lr, float beta1, float beta2, float eps,
                  float weight_decay, int step, const void* gnorm_sq, float max_norm, capdec_stream_t stream);
 
+/* ---- cross-attention branch over a memory of ONE position (S = 1, ref models.py:104) ------------------
+ * Softmax over one key is 1: head h's context is v[b, h-slice], kept or dropped as a whole by the
+ * attention-probability dropout, so the branch  addend + dropout_out(out_proj(context) + bias)
+ * (torch/nn/modules/transformer.py:1177-1187 with F.multi_head_attention_forward, functional.py:6613-6642)
+ * needs no [B*T, d] x [d, d] product:
+ *   U[b*H+h, :] = Wo[:, h-slice] v[b, h-slice]                         (the caller's tiny GEMM, B*H rows)
+ *   capdec_cross1_fwd: out[r,:] = addend[r,:] + drop_out(bias + sum_h keep_h(r)/(1-p_attn) * U[(r/T)*H+h, :])
+ *   capdec_cross1_bwd: dU[b*H+h,:] = sum_t keep_h(b,t)/(1-p_attn) * g[b*T+t,:];  dbias_part[b,:] = sum_t g[b*T+t,:]
+ * with g the gradient at the branch output AFTER the output dropout's mask.  Element indices of both
+ * dropouts are those of capdec_attn_fwd (Tk = 1) and of capdec_gemm's epilogue; all rows dense (ld = d);
+ * d % 64 == 0; H in {1,2,4,8,16} for the backward.  Fixed summation orders (bitwise reproducible). */
+int capdec_cross1_fwd(const void* U, const void* bias, const void* addend, void* out, int B, int T, int H, int d,
+                      float attn_p, uint64_t attn_seed, float out_p, uint64_t out_seed, capdec_stream_t stream);
+int capdec_cross1_bwd(const void* g, void* dU, void* dbias_part, int B, int T, int H, int d, float attn_p,
+                      uint64_t attn_seed, capdec_stream_t stream);
+
 /* ---- KV-cached decode step: greedy / beam search (NEW capability: the reference only samples,
  * ref train.py:338-368, and re-runs the whole prefix every step, train.py:312-332) ----------------
  * capdec_decode_attn: single-query attention of every row r (R = images * W beams) against

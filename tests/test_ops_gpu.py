@@ -463,3 +463,53 @@ def test_attention_single_key_streaming_path(B, H, Tq, dh, p):
         w = keep.unsqueeze(-1).float() / (1 - p)
         assert relerr(o, (w * vb.view(B, Tq, H, dh)).reshape(B * Tq, D)) < 1e-6
         assert relerr(dv, (w * do.view(B, Tq, H, dh)).double().sum(1).reshape(B, D)) < 1e-5
+
+
+@pytest.mark.parametrize("B,T,H,d,p", [(3, 7, 2, 64, 0.0), (4, 33, 8, 512, 0.1), (2, 299, 8, 512, 0.1), (1, 1, 4, 128, 0.3)])
+def test_single_key_cross_branch_equals_attention_plus_out_projection(B, T, H, d, p):
+    """capdec_cross1_fwd / _bwd (memory of ONE position) against the generic kernels they replace -- single-key
+    attention (same probability-dropout mask) followed by the out-projection GEMM with its fused output dropout
+    and residual -- forward and all gradients (dWo, dbo, dv), and against plain float64 math when p = 0."""
+    from imagecaption_amd import ops
+    g = torch.Generator().manual_seed(B * 100 + T)
+    dh = d // H
+    v = torch.randn(B, d, generator=g).to(DEV)
+    k = torch.randn(B, d, generator=g).to(DEV)
+    x1 = torch.randn(B * T, d, generator=g).to(DEV)
+    wo = (torch.randn(d, d, generator=g) / d ** 0.5).to(DEV)
+    bo = torch.randn(d, generator=g).to(DEV)
+    gout = torch.randn(B * T, d, generator=g).to(DEV)
+    sa, so = 1234567, 7654321
+    # generic path
+    c, _ = ops.attn_fwd(x1, k, v, B, H, T, 1, False, p, sa, save_lse=False)
+    s2_ref = ops.linear_fwd(c, wo, bo, drop_p=p, seed=so, addend=x1)
+    # gradient at the branch output after the output dropout's mask (what layernorm_bwd hands over)
+    ones = torch.ones_like(gout)
+    mask = ops.linear_fwd(torch.zeros_like(c), wo, torch.ones_like(bo), drop_p=p, seed=so, addend=None)  # = keep/(1-p)
+    gm = gout * mask
+    dwo_ref = torch.empty_like(wo); dbo_ref = torch.empty_like(bo)
+    ops.linear_wgrad(gm, c, dw=dwo_ref, db=dbo_ref)
+    dc = ops.linear_dgrad(gm, wo)
+    dkv = torch.empty(B, 2 * d, device=DEV)
+    ops.attn_bwd(x1, k, v, c, dc, None, B, H, T, 1, False, p, sa, dk=dkv[:, :d], dv=dkv[:, d:], need_dq=False)
+    # streaming path
+    eye = torch.eye(H, device=DEV)
+    vblk = (v.reshape(B, 1, H, dh) * eye.view(1, H, H, 1)).reshape(B * H, d)
+    U = ops.linear_fwd(vblk, wo)
+    s2 = ops.cross1_fwd(U, bo, x1, B, T, H, p, sa, p, so)
+    scale = float(s2_ref.abs().max())
+    assert float((s2 - s2_ref).abs().max()) < 2e-5 * scale
+    dU, dbp = ops.cross1_bwd(gm, B, T, H, p, sa)
+    dwo = torch.empty_like(wo)
+    ops.linear_wgrad(dU, vblk, dw=dwo)
+    dvblk = ops.linear_dgrad(dU, wo)
+    dv = torch.diagonal(dvblk.view(B, H, H, dh), dim1=1, dim2=2).permute(0, 2, 1).reshape(B, d)
+    torch.cuda.synchronize()
+    for got, ref in ((dwo, dwo_ref), (dbp.sum(0), dbo_ref), (dv, dkv[:, d:])):
+        assert float((got - ref).abs().max()) < 1e-4 * max(float(ref.abs().max()), 1e-6)
+    if p == 0.0:
+        ctx = v.double().view(B, 1, d).expand(B, T, d).reshape(B * T, d)
+        want = ctx @ wo.double().t() + bo.double() + x1.double()
+        assert float((s2.double() - want).abs().max()) < 2e-5 * scale
+    a = ops.cross1_fwd(U, bo, x1, B, T, H, p, sa, p, so)
+    assert torch.equal(a, s2)                                      # deterministic

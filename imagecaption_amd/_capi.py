@@ -91,7 +91,15 @@ def ptr(t):
     return None if t is None else t.data_ptr()
 
 
+try:  # the raw handle of torch's current stream without building a torch.cuda.Stream object (~8 us -> < 1 us per op)
+    _raw_stream, _cur_device = torch._C._cuda_getCurrentRawStream, torch._C._cuda_getDevice
+except AttributeError:  # CPU-only torch builds / future renames: the public, slower path
+    _raw_stream = _cur_device = None
+
+
 def stream():
+    if _raw_stream is not None:
+        return _raw_stream(_cur_device())
     return torch.cuda.current_stream().cuda_stream
 
 

@@ -59,19 +59,18 @@ class CaptionDecoder:
         dh = d // H
         scale = 1.0 / math.sqrt(dh)
         l = lib()
-        x = ops.embed_fwd(tok.view(R, 1), m.embedding.weight, m.pos_encoder.table(), t0=t).view(R, d)
+        x = ops.embed_fwd(tok.view(R, 1), m.embedding.weight, st["pe"], t0=t).view(R, d)
+        anc = ptr(st["anc"][st["cur"]])
         for li, P in enumerate(self.layers):
-            w_in, b_in = P["self_attn.in_proj_weight"], P["self_attn.in_proj_bias"]
-            q = ops.linear_fwd(x, w_in[:d], b_in[:d])
+            V = st["views"][li]  # weight / cache slices made once per decode call (a slice costs ~1.5 us of host time)
+            q = ops.linear_fwd(x, V["wq"], V["bq"])
             cache = st["cache"][li]  # [N*W, Tmax, 2d]
-            ops.linear_fwd(x, w_in[d:], b_in[d:], out=cache[::every, t, :])  # scatter via the output row stride
+            ops.linear_fwd(x, V["wkv"], V["bkv"], out=cache[::every, t, :])  # scatter via the output row stride
             a = torch.empty((R, d), dtype=torch.float32, device=x.device)
-            c2 = cache.view(-1, 2 * d)
-            check(l.capdec_decode_attn(ptr(q), d, ptr(c2), ptr(c2[:, d:]), 2 * d, ptr(a), d, ptr(st["anc"][st["cur"]]),
+            check(l.capdec_decode_attn(ptr(q), d, V["c2k"], V["c2v"], 2 * d, ptr(a), d, anc,
                                        R, H, dh, Tmax, t, W, S, scale, stream()), "capdec_decode_attn")
             s1 = ops.linear_fwd(a, P["self_attn.out_proj.weight"], P["self_attn.out_proj.bias"], addend=x)
             x1, _, _ = ops.layernorm_fwd(s1, P["norm1.weight"], P["norm1.bias"], save_stats=False)
-            wc, bc = P["multihead_attn.in_proj_weight"], P["multihead_attn.in_proj_bias"]
             if S == 1:
                 # one key (ref models.py:104): the context is that key's value whatever the query, so the whole
                 # cross-attention branch out_proj(v) + bias is a per-image constant, computed once in _prepare;
@@ -79,10 +78,9 @@ class CaptionDecoder:
                 u = st["cross_out"][li]
                 s2 = (u if W == 1 else u.repeat_interleave(W, dim=0)) + x1
             else:
-                q = ops.linear_fwd(x1, wc[:d], bc[:d])
-                kv = st["cross_kv"][li]  # [N*S, 2d]
+                q = ops.linear_fwd(x1, V["wcq"], V["bcq"])
                 c = torch.empty((R, d), dtype=torch.float32, device=x.device)
-                check(l.capdec_decode_attn(ptr(q), d, ptr(kv), ptr(kv[:, d:]), 2 * d, ptr(c), d, None, R, H, dh, Tmax, t,
+                check(l.capdec_decode_attn(ptr(q), d, V["kvk"], V["kvv"], 2 * d, ptr(c), d, None, R, H, dh, Tmax, t,
                                            W, S, scale, stream()), "capdec_decode_attn")
                 s2 = ops.linear_fwd(c, P["multihead_attn.out_proj.weight"], P["multihead_attn.out_proj.bias"], addend=x1)
             x2, _, _ = ops.layernorm_fwd(s2, P["norm2.weight"], P["norm2.bias"], save_stats=False)
@@ -111,8 +109,18 @@ class CaptionDecoder:
                     cross.append(ops.linear_fwd(mem, wc[d:], bc[d:]))
                     cross_out.append(None)
         R = N * W
-        st = dict(N=N, W=W, R=R, S=S, Tmax=Tmax, cross_kv=cross, cross_out=cross_out, cur=0,
-                  cache=[torch.empty((R, Tmax, 2 * d), dtype=torch.float32, device=dev) for _ in self.layers],
+        cache = [torch.empty((R, Tmax, 2 * d), dtype=torch.float32, device=dev) for _ in self.layers]
+        views = []
+        for li, P in enumerate(self.layers):
+            w_in, b_in = P["self_attn.in_proj_weight"], P["self_attn.in_proj_bias"]
+            wc, bc = P["multihead_attn.in_proj_weight"], P["multihead_attn.in_proj_bias"]
+            c2 = cache[li].view(-1, 2 * d)
+            views.append(dict(wq=w_in[:d], bq=b_in[:d], wkv=w_in[d:], bkv=b_in[d:], wcq=wc[:d], bcq=bc[:d],
+                              c2k=ptr(c2), c2v=ptr(c2[:, d:]), kvk=ptr(cross[li]),
+                              kvv=None if cross[li] is None else ptr(cross[li][:, d:])))
+        st = dict(N=N, W=W, R=R, S=S, Tmax=Tmax, cross_kv=cross, cross_out=cross_out, cur=0, views=views,
+                  pe=m.pos_encoder.table(),
+                  cache=cache,
                   anc=[torch.arange(R, dtype=torch.int32, device=dev).view(R, 1).repeat(1, Tmax).contiguous()
                        for _ in range(2)],
                   seq=[torch.zeros((R, Tmax), dtype=torch.int32, device=dev) for _ in range(2)])

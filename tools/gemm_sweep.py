@@ -32,18 +32,21 @@ for ta, tb, M, N, K in SHAPES:
     out = torch.empty(M, N, device="cuda")
     res = []
     l.capdec_gemm_tune(0, 0, 0, 0)
+    ops._WS_NEED.clear()
     t = timeit(lambda: ops.gemm(a, b, ta, tb, out=out))
     res.append(("auto", t))
     for (bm, bn), sp, bk in itertools.product(CANDS, [1, 2, 4, 8, 16], BKS):
         if sp > 1 and K // sp < 128: continue
         if sp > 1 and M * N * sp * 4 > (1 << 30): continue
         l.capdec_gemm_tune(bm, bn, sp, bk)
+        ops._WS_NEED.clear()  # the workspace need depends on the forced plan
         try:
             t = timeit(lambda: ops.gemm(a, b, ta, tb, out=out))
         except Exception as e:
             continue
         res.append((f"{bm}x{bn}x{bk}/s{sp}", t))
     l.capdec_gemm_tune(0, 0, 0, 0)
+    ops._WS_NEED.clear()
     fl = 2.0 * M * N * K
     res.sort(key=lambda r: r[1])
     auto = [r for r in res if r[0] == "auto"][0]

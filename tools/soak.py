@@ -1,0 +1,43 @@
+"""Soak: the C2 training step run N times twice from the same seed must end in bitwise identical parameters (the side
+lane, shared workspaces and batched K/V products leave no room for a race), with a finite, decreasing loss; then
+beam / sampler decode twice -> identical ids."""
+import os, sys, time
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import torch
+import bench
+from imagecaption_amd import ImageCaptioningModel
+from imagecaption_amd.trainer import CaptionTrainer
+from imagecaption_amd.decode import CaptionDecoder
+
+steps = int(sys.argv[1]) if len(sys.argv) > 1 else 300
+cfg = bench.CONFIGS["c2"]
+dev = torch.device("cuda")
+f, c = bench.synth_batch(cfg, cfg["batch"], dev, 0)
+
+def run():
+    torch.manual_seed(42)
+    model = ImageCaptioningModel(cfg["vocab"], cfg["d"], cfg["heads"], cfg["layers"], feature_dim=cfg["din"]).to(dev).train()
+    tr = CaptionTrainer(model, dropout=0.1, seed=42)
+    losses = []
+    for i in range(steps):
+        loss = tr.step(f, c)
+        if i % 50 == 0 or i == steps - 1:
+            losses.append(float(loss.item()))
+    torch.cuda.synchronize()
+    return model, tr.flat_p.clone(), losses
+
+t0 = time.perf_counter()
+m1, p1, l1 = run()
+m2, p2, l2 = run()
+print("losses", [round(x, 4) for x in l1], flush=True)
+assert all(map(lambda x: x == x and abs(x) < 1e4, l1)), "non-finite loss"
+assert l1[-1] < l1[0], "loss did not decrease"
+assert l1 == l2 and torch.equal(p1, p2), "training is not bitwise reproducible"
+print(f"train: {steps} steps x 2 bitwise identical, {time.perf_counter() - t0:.1f} s", flush=True)
+dec = CaptionDecoder(m1.eval())
+feats = f[:64]
+a = dec.beam(feats, 3, 20); b = dec.beam(feats, 3, 20)
+assert torch.equal(a[0], b[0]) and torch.equal(a[1], b[1])
+s1 = dec.sample(feats, max_len=40, seed=3); s2 = dec.sample(feats, max_len=40, seed=3)
+assert torch.equal(s1, s2)
+print("decode: beam-3 and sampler bitwise identical on the trained weights", flush=True)

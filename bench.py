@@ -255,6 +255,12 @@ def main():
     ap.add_argument("--detail", action="store_true", help="print the per-shape kernel table to stderr")
     ap.add_argument("--no-modes", action="store_true", help="skip the f32x3 / bf16 legs of the default fp32 run")
     args = ap.parse_args()
+    # The contract is ONE JSON line on stdout.  Libraries write there too (RCCL prints a version banner when its
+    # first communicator is built), so file descriptor 1 points at stderr for the whole run and is restored only
+    # to print the result line.
+    sys.stdout.flush()
+    saved_stdout = os.dup(1)
+    os.dup2(2, 1)
     if os.environ.get("CAPDEC_HANG_DUMP"):  # debugging aid: dump every thread's stack after N seconds and exit
         import faulthandler
         faulthandler.dump_traceback_later(int(os.environ["CAPDEC_HANG_DUMP"]), exit=True)
@@ -363,6 +369,8 @@ def main():
                       + (f"  {d[2] / d[3] / 1e9:8.1f} GB/s" if d[2] else ""), file=sys.stderr)
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(cfg)
+        sys.stdout.flush()
+        os.dup2(saved_stdout, 1)
         print(json.dumps(out), flush=True)
     if world > 1 or forced:
         dist.barrier()

@@ -5,8 +5,8 @@ import torch
 from imagecaption_amd import ops, _capi
 ops.COMPUTE_DTYPE = {"fp32": _capi.F32, "bf16": _capi.BF16, "f32x3": _capi.F32X3}[os.environ.get("GEMM_DTYPE", "fp32")]
 if os.environ.get("GEMM_TILE"):
-    bm, bn, sp = [int(x) for x in os.environ["GEMM_TILE"].split(",")]
-    _capi.lib().capdec_gemm_tune(bm, bn, sp, 0)
+    bm, bn, sp, bk = ([int(x) for x in os.environ["GEMM_TILE"].split(",")] + [0])[:4]   # "bm,bn,split[,bk]"
+    _capi.lib().capdec_gemm_tune(bm, bn, sp, bk)
 ta, tb, M, N, K = [int(x) for x in sys.argv[1:6]]
 a = torch.randn((K, M) if ta else (M, K), device="cuda")
 b = torch.randn((N, K) if tb else (K, N), device="cuda")

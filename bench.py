@@ -237,6 +237,67 @@ def timed_steps(trainer, feats, ids, steps, warmup, world, dev):
     return dt, loss
 
 
+def _free_port():
+    import socket
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    return port
+
+
+def launch_ranks(n, argv):
+    """``python bench.py --gpus N`` without a launcher: start N rank processes (one per GPU) through
+    ``torch.distributed.run`` as FRESH children -- this parent has made no GPU call and makes none -- relay
+    their stderr, and print rank 0's single JSON line.  Returns the exit code."""
+    import subprocess
+    port = os.environ.get("MASTER_PORT") or str(_free_port())
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={n}",
+           "--master-addr", "127.0.0.1", "--master-port", port, os.path.abspath(__file__)] + list(argv)
+    env = dict(os.environ)
+    env.pop("MASTER_PORT", None)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")  # dmabuf IPC only on this pool (RCCL needs it)
+    r = subprocess.run(cmd, env=env, stdout=subprocess.PIPE, text=True)
+    lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{") and ln.rstrip().endswith("}")]
+    if r.returncode != 0 or not lines:
+        sys.stderr.write(r.stdout)
+        print(f"bench.py: the {n}-rank run failed (exit code {r.returncode}, {len(lines)} result line(s))", file=sys.stderr)
+        return r.returncode or 1
+    print(lines[-1], flush=True)
+    return 0
+
+
+def launch_check(world, rank, saved_stdout):
+    """--launch-check: every rank joins the process group, takes part in one all-reduce and rank 0 reports the
+    group size -- the launcher / rendezvous path of ``--gpus N`` without any kernel (runs on CPU with gloo)."""
+    use_gpu = torch.cuda.device_count() > 0 and os.environ.get("CAPDEC_DIST_BACKEND", "nccl") == "nccl"
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        if use_gpu:
+            lr = int(os.environ.get("LOCAL_RANK", "0"))
+            torch.cuda.set_device(lr)
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", lr))
+        else:
+            dist.init_process_group("gloo", rank=rank, world_size=world)
+    ones = torch.ones(4, device="cuda" if (use_gpu and world > 1) else "cpu")
+    if world > 1:
+        dist.all_reduce(ones)
+    ranks = dist.get_world_size() if world > 1 else 1
+    ok = bool((ones == float(world)).all().item())
+    if world > 1:
+        dist.barrier()
+        backend = dist.get_backend()
+        dist.destroy_process_group()
+    else:
+        backend = None
+    if rank == 0:
+        sys.stdout.flush()
+        os.dup2(saved_stdout, 1)
+        print(json.dumps({"metric": "launch_check", "n_gpus": world, "rccl_ranks": ranks, "backend": backend,
+                          "allreduce_ok": ok}), flush=True)
+    return 0 if ok else 1
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -254,7 +315,13 @@ def main():
                     help="images per GPU for the decode leg (BASELINE configs[4]: 100k images over 8 GPUs)")
     ap.add_argument("--detail", action="store_true", help="print the per-shape kernel table to stderr")
     ap.add_argument("--no-modes", action="store_true", help="skip the f32x3 / bf16 legs of the default fp32 run")
+    ap.add_argument("--launch-check", action="store_true",
+                    help="only start the ranks, all-reduce once and report the group size (no kernels; works on CPU)")
     args = ap.parse_args()
+    # `python bench.py --gpus N` (N > 1) outside a launcher: start the N ranks here.  Nothing above or in
+    # launch_ranks touches the GPU, so the children are fresh processes of a parent without a HIP context.
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        sys.exit(launch_ranks(args.gpus, sys.argv[1:]))
     # The contract is ONE JSON line on stdout.  Libraries write there too (RCCL prints a version banner when its
     # first communicator is built), so file descriptor 1 points at stderr for the whole run and is restored only
     # to print the result line.
@@ -268,6 +335,10 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if args.gpus > 1 and args.gpus != world:
+        raise SystemExit(f"bench.py: --gpus {args.gpus} but the launcher started WORLD_SIZE={world} ranks")
+    if args.launch_check:
+        sys.exit(launch_check(world, rank, saved_stdout))
     # rehearsal hooks (tests only): CAPDEC_DIST_BACKEND=gloo + CAPDEC_SINGLE_DEVICE=1 run N ranks on one GPU
     backend = os.environ.get("CAPDEC_DIST_BACKEND", "nccl")
     if os.environ.get("CAPDEC_SINGLE_DEVICE") == "1":
@@ -337,6 +408,9 @@ def main():
         vocab = detail.get(vk)
         out = {
             "metric": "train_images_per_sec", "value": value, "unit": "images/s", "n_gpus": world,
+            # size of the process group the gradient all-reduce really ran on (RCCL when backend == "nccl")
+            "rccl_ranks": dist.get_world_size() if dist.is_initialized() else 1,
+            "dist_backend": dist.get_backend() if dist.is_initialized() else None,
             "steps": args.steps, "warmup": args.warmup, "ms_per_step": ms, "higher_is_better": True,
             "scaling": "weak", "vs_baseline": None, "dtype": {"fp32": "f32", "f32x3": "f32 (3 x bf16 split operands, six bf16 MFMA products)", "bf16": "bf16"}[args.dtype], "data": "synthetic",
             "config": {"workload": f"BASELINE.json configs[1] (C2): 7x7x2048 grid features, hidden {cfg['d']}, "

@@ -105,3 +105,26 @@ def test_dropout_plan_seeds():
     assert DropoutPlan(0.1, 42, 8).seed(3) != a.seed(3)
     assert DropoutPlan(0.0).p == 0.0
     assert 0 <= a.seed(1000) < 2 ** 64
+
+
+def test_bench_gpus_flag_launches_that_many_ranks():
+    """`python bench.py --gpus 2` outside a launcher must start two rank processes itself.
+    --launch-check stops after the rendezvous and one all-reduce, so this runs without a GPU (gloo)."""
+    import json
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_PORT")}
+    env["CAPDEC_DIST_BACKEND"] = "gloo"
+    r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--launch-check"], env=env,
+                       capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0, r.stderr[-2000:]
+    lines = [ln for ln in r.stdout.splitlines() if ln.strip()]
+    assert len(lines) == 1, r.stdout  # the contract: ONE JSON line on stdout
+    out = json.loads(lines[0])
+    assert out["n_gpus"] == 2 and out["rccl_ranks"] == 2 and out["allreduce_ok"]
+    # a launcher that started a different number of ranks than --gpus asks for is an error, not a silent 1-rank run
+    env2 = dict(env, WORLD_SIZE="1", RANK="0", LOCAL_RANK="0")
+    r2 = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--launch-check"], env=env2,
+                        capture_output=True, text=True, timeout=300)
+    assert r2.returncode != 0 and "WORLD_SIZE=1" in r2.stderr

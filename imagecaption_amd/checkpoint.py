@@ -17,13 +17,27 @@ This build keeps no ViT (``model.vit`` is whatever feature extractor the caller 
   the file is decoder-only (``strict=False`` on the reference side).
 
 Files are read with ``torch.load(..., weights_only=True)`` only: nothing in a checkpoint is executed.
-A file the safe loader refuses (e.g. numpy scalars among the metrics) is reported, not force-loaded.
+The reference's ``metrics`` dict holds ``np.mean(...)`` results (ref train.py:251-264 -> numpy.float64), which
+pickle through ``numpy._core.multiarray.scalar`` + a dtype class; those data constructors (and nothing else)
+are allow-listed for the load.  A file the safe loader still refuses is reported, not force-loaded.
 """
+import numpy as np
 import torch
 
 VIT_PREFIX = "vit."
 KEYS = ("epoch", "model_state_dict", "optimizer_state_dict", "scheduler_state_dict", "loss", "metrics",
         "vocab_size", "vocab_idx2word", "initial_lr")
+
+
+def _numpy_scalar_globals():
+    """What a pickled numpy scalar needs: the scalar re-constructor, ``numpy.dtype`` and the dtype classes of the
+    numeric types a metrics dict can hold.  They rebuild a number from raw bytes and execute no code."""
+    try:
+        scalar = np._core.multiarray.scalar   # numpy >= 2
+    except AttributeError:                  # numpy 1.x
+        scalar = np.core.multiarray.scalar
+    kinds = ("float64", "float32", "float16", "int64", "int32", "int16", "int8", "uint8", "bool")
+    return [scalar, np.dtype] + sorted({type(np.dtype(k)) for k in kinds}, key=lambda c: c.__name__)
 
 
 def split_state_dict(sd):
@@ -56,7 +70,8 @@ def load_reference_checkpoint(path, model, optimizer=None, scheduler=None, map_l
     ``CaptionTrainer``.  Returns the checkpoint dict with ``model_state_dict`` replaced by the
     ``vit.*`` remainder (for the caller's feature extractor) under ``vit_state_dict``."""
     try:
-        ckpt = torch.load(path, map_location=map_location, weights_only=True)
+        with torch.serialization.safe_globals(_numpy_scalar_globals()):
+            ckpt = torch.load(path, map_location=map_location, weights_only=True)
     except Exception as e:  # the safe loader refused: say so, never fall back to unpickling
         raise RuntimeError(f"{path}: torch.load(weights_only=True) refused this file ({e}); it is not loaded") from e
     if "model_state_dict" not in ckpt:

@@ -22,7 +22,10 @@ __device__ __forceinline__ float block_max_256(float v, float* sh) {
 
 // One 256-thread block per row.  Pass 1: max and sum(z).  Pass 2: sum(exp(z - max)).
 // Pass 3 (optional): dlogits.  The row (<= 120 KB) stays in L2 between passes.
-__global__ __launch_bounds__(256) void softmax_ce_kernel(const float* __restrict__ logits, int ldl,
+// dlogits may alias logits (in-place mode), so neither pointer is __restrict__; everything the loss row needs
+// from the logits (z_y included) is read BEFORE the last block-wide barrier, i.e. before any thread can store a
+// gradient over it.
+__global__ __launch_bounds__(256) void softmax_ce_kernel(const float* logits, int ldl,
                                                           const int64_t* __restrict__ targets,
                                                           float* __restrict__ loss_rows, float* dlogits, int lddl, int V,
                                                           float eps, float grad_scale) {
@@ -39,11 +42,12 @@ __global__ __launch_bounds__(256) void softmax_ce_kernel(const float* __restrict
     sz = block_sum_256(sz, sh);
     float se = 0.f;
     for (int v = threadIdx.x; v < V; v += 256) se += __expf(z[v] - mx);
-    se = block_sum_256(se, sh);
-    const float lse = mx + __logf(se);
     int64_t y = targets[m];
     y = y < 0 ? 0 : (y >= V ? V - 1 : y);
-    if (threadIdx.x == 0 && loss_rows) loss_rows[m] = lse - (1.f - eps) * z[y] - (eps / (float)V) * sz;
+    const float zy = z[y];
+    se = block_sum_256(se, sh);  // barrier: every read above is ordered before every store below
+    const float lse = mx + __logf(se);
+    if (threadIdx.x == 0 && loss_rows) loss_rows[m] = lse - (1.f - eps) * zy - (eps / (float)V) * sz;
     if (dlogits) {
         float* dz = dlogits + (size_t)m * lddl;
         const float u = eps / (float)V;

@@ -3,6 +3,7 @@
 CPU only: a synthetic 'reference' model = fake ViT (parameters only, registered first) + the oracle's
 decoder-path modules, trained one AdamW step, saved exactly as the reference saves."""
 
+import numpy as np
 import pytest
 import torch
 
@@ -39,7 +40,11 @@ def _trained_reference(tmp_path):
     opt.step()
     path = str(tmp_path / "best_model.pth")
     torch.save({"epoch": 3, "model_state_dict": ref.state_dict(), "optimizer_state_dict": opt.state_dict(),
-                "scheduler_state_dict": sched.state_dict(), "loss": 1.25, "metrics": {"bleu4": 0.125},
+                "scheduler_state_dict": sched.state_dict(), "loss": 1.25,
+                # exactly what evaluate_metrics returns (ref train.py:251-264, 280-287): corpus_bleu gives Python
+                # floats, the other four are np.mean(...) results, i.e. numpy.float64 scalars in the pickle
+                "metrics": {"bleu1": 0.5, "bleu4": 0.125, "meteor": np.mean([0.25, 0.5]), "rouge_l": np.mean([0.5]),
+                            "cider": np.mean([1.0, 2.0]), "spice": np.mean([0.125, 0.25])},
                 "vocab_size": 50, "vocab_idx2word": {0: "<PAD>", 1: "<START>"}, "initial_lr": 1e-3}, path)  # train.py:485-495
     return ref, opt, path
 
@@ -52,6 +57,7 @@ def test_load_reference_checkpoint_into_model_and_torch_adamw(tmp_path):
     opt = torch.optim.AdamW(model.parameters(), lr=5e-4, weight_decay=0.01)
     info = load_reference_checkpoint(path, model, opt)
     assert info["epoch"] == 3 and info["vocab_size"] == 50 and info["vocab_idx2word"][1] == "<START>"
+    assert info["metrics"]["bleu4"] == 0.125 and float(info["metrics"]["meteor"]) == 0.375  # numpy scalars load
     assert sorted(info["vit_state_dict"]) == sorted(k for k in ref.state_dict() if k.startswith("vit."))
     rsd = ref.state_dict()
     for k, v in model.state_dict().items():

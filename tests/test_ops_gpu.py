@@ -288,8 +288,11 @@ def test_softmax_ce(M, V):
     assert abs(mean.item() - loss_ref.mean().item()) < 1e-5 * abs(loss_ref.mean().item())
     # in-place variant
     zz = z.detach().float().to(DEV)
-    _, dl2 = ops.softmax_ce(zz, y.to(DEV), 0.1, in_place=True)
+    rows2, dl2 = ops.softmax_ce(zz, y.to(DEV), 0.1, in_place=True)
     assert dl2.data_ptr() == zz.data_ptr() and torch.equal(dl2, dl)
+    # the in-place call's loss rows read z[y] while other waves overwrite the row: targets spread over every wave
+    # of the block (ids >= 64 included) must give the bits of the out-of-place call
+    assert torch.equal(rows2, rows)
 
 
 def test_sumsq_and_adamw_against_torch_optim():

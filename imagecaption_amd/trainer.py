@@ -27,18 +27,48 @@ from .engine import DropoutPlan
 from .parallel import BucketReducer, FlatParams, decoder_param_groups
 
 
+class FusedAdamW(torch.optim.Optimizer):
+    """The optimizer object the reference's driver code expects (ref main.py:95-104), backed by the trainer's
+    fused clip + AdamW kernel over the flat blocks.  It IS a ``torch.optim.Optimizer``, so
+    ``ReduceLROnPlateau(optimizer, ...)`` accepts it (ref main.py:98-104) and the warm-up loop's
+    ``for g in optimizer.param_groups: g['lr'] = ...`` (ref train.py:436-447) and ``scheduler.step(bleu4)``
+    (train.py:460) steer the kernel: ``CaptionTrainer.optimizer_step`` reads lr / betas / eps / weight_decay from
+    ``param_groups[0]`` on every step.  One group over ``model.parameters()`` (what the reference builds);
+    ``state_dict`` / ``load_state_dict`` speak ``torch.optim.AdamW``'s format (checkpoints, ref train.py:485-495)."""
+
+    def __init__(self, trainer, params, lr, betas, eps, weight_decay):
+        super().__init__(params, dict(lr=lr, betas=tuple(betas), eps=eps, weight_decay=weight_decay))
+        self._trainer = trainer
+
+    def step(self, closure=None):
+        loss = closure() if closure is not None else None
+        self._trainer.optimizer_step()
+        return loss
+
+    def zero_grad(self, set_to_none=False):
+        """No-op: every gradient is fully overwritten by the step's kernels, and the ``.grad`` views into the flat
+        block must stay in place (the stock ``set_to_none=True`` would drop them)."""
+
+    def state_dict(self):
+        return self._trainer.adamw_state_dict()
+
+    def load_state_dict(self, sd):
+        self._trainer.load_adamw_state_dict(sd)
+
+
 class CaptionTrainer:
     def __init__(self, model, lr=1e-3, betas=(0.9, 0.999), eps=1e-8, weight_decay=0.01, max_norm=1.0,
                  smooth_factor=0.1, dropout=0.1, seed=0, process_group=None, overlap=True, dtype="fp32",
                  side_stream_wgrad=True):
         self.model = model
-        self.lr, self.betas, self.eps, self.wd = lr, betas, eps, weight_decay
+        self.optimizer = FusedAdamW(self, list(model.parameters()), lr, betas, eps, weight_decay)
         self.max_norm, self.smooth, self.p, self.seed = max_norm, smooth_factor, dropout, seed
         self.pg = process_group
         # "fp32" (exact fp32 MFMA, the reference's precision), "f32x3" (split-bf16 products, fp32-level accuracy)
         # or "bf16" (bf16 MFMA products, fp32 everything else)
         self.dtype = dtype
         self.world = dist.get_world_size(process_group) if (dist.is_available() and dist.is_initialized()) else 1
+        self.rank = dist.get_rank(process_group) if self.world > 1 else 0
         self.step_count = 0
         dec = model.transformer_decoder
         self.nhead, self.nl = dec.nhead, len(dec.layers)
@@ -58,7 +88,36 @@ class CaptionTrainer:
         self.reducer = BucketReducer(self.flat_g, self.bucket_ranges, process_group, overlap)
         self._logits = None
         self.side = ops.SideStream(dev) if (side_stream_wgrad and dev.type == "cuda") else None
+        self._rows = None  # B*T of the first step; data-parallel ranks must all run this many rows (1/(rows*world))
+        if self.world > 1:
+            # every rank must start from the same parameters (the ranks only ever exchange gradients): rank 0's win
+            dist.broadcast(self.flat_p, src=dist.get_global_rank(process_group, 0) if process_group is not None else 0,
+                           group=process_group)
         self._refresh_views()
+
+    # lr / betas / eps / weight_decay live in the optimizer facade's param_groups[0]: that is where the reference's
+    # warm-up loop and ReduceLROnPlateau write them (ref train.py:436-447, 460)
+    def _group_get(self, key):
+        return self.optimizer.param_groups[0][key]
+
+    def _group_set(self, key, value):
+        for g in self.optimizer.param_groups:
+            g[key] = value
+
+    lr = property(lambda self: self._group_get("lr"), lambda self, v: self._group_set("lr", v))
+    betas = property(lambda self: self._group_get("betas"), lambda self, v: self._group_set("betas", tuple(v)))
+    eps = property(lambda self: self._group_get("eps"), lambda self, v: self._group_set("eps", v))
+    wd = property(lambda self: self._group_get("weight_decay"), lambda self, v: self._group_set("weight_decay", v))
+
+    def _check_equal_rows(self, rows):
+        """The loss gradient is pre-scaled by 1/(rows * world): exact only if every rank runs the same B*T."""
+        if self.world > 1 and self._rows != rows:
+            t = torch.tensor([rows, -rows], dtype=torch.int64, device=self.flat_p.device)
+            dist.all_reduce(t, op=dist.ReduceOp.MAX, group=self.pg)
+            if int(t[0]) != -int(t[1]):
+                raise RuntimeError(f"CaptionTrainer: ranks run different batch shapes (B*T between {-int(t[1])} and "
+                                   f"{int(t[0])}); data-parallel steps need equal per-rank batches")
+        self._rows = rows
 
     def _refresh_views(self):
         m = self.model
@@ -88,7 +147,11 @@ class CaptionTrainer:
         tgt_in = captions[:, :-1].contiguous()   # ref train.py:29
         tgt_out = captions[:, 1:].contiguous()   # ref train.py:30
         B, T = tgt_in.shape
-        dp = DropoutPlan(self.p if train else 0.0, self.seed, self.step_count)
+        self._check_equal_rows(B * T)
+        # each rank draws its own dropout masks (rank folded into the key): the same masks on different data would
+        # correlate the noise across the global batch
+        dp = DropoutPlan(self.p if train else 0.0, self.seed ^ engine._splitmix64(self.rank) if self.rank else self.seed,
+                         self.step_count)
         f2 = features.reshape(-1, features.shape[-1])
         S = 1 if features.dim() == 2 else features.shape[1]
         sv_proj, sv_stack, sv_head = {}, {}, {}
@@ -161,6 +224,9 @@ class CaptionTrainer:
         opt.load_state_dict(sd)
         g = opt.param_groups[0]
         self.lr, self.betas, self.eps, self.wd = g["lr"], tuple(g["betas"]), g["eps"], g["weight_decay"]
+        for k, v in g.items():  # scheduler bookkeeping such as 'initial_lr' travels with the group
+            if k not in ("params", "lr", "betas", "eps", "weight_decay"):
+                self._group_set(k, v)
         off = {id(p): o for p, o in self.flat.placed}
         self.flat_m.zero_()
         self.flat_v.zero_()

@@ -63,7 +63,8 @@ def test_reference_checkpoint_resumes_on_device_and_next_step_matches_oracle(tmp
         feats = ref.vit(x)  # the encoder stays on the caller's side; the decoder path gets its features
         want = ref(x, caps[:, :-1])
     model.eval()
-    got = model(feats.to(DEV), caps[:, :-1].to(DEV))
+    mask = model.generate_square_subsequent_mask(caps.shape[1] - 1)  # ref train.py:33
+    got = model(feats.to(DEV), caps[:, :-1].to(DEV), mask)            # ref train.py:38
     assert relerr(got, want) < 5e-5
     # the NEXT step: moments, step counter (bias correction) and lr all come from the file
     loss_ref = _oracle_step(ref, opt, x, caps)
@@ -71,8 +72,14 @@ def test_reference_checkpoint_resumes_on_device_and_next_step_matches_oracle(tmp
     assert abs(loss.item() - loss_ref) < 1e-5 * abs(loss_ref)
     rparams = {n: p for n, p in ref.named_parameters() if not n.startswith("vit.")}
     for n, p in model.named_parameters():
-        # third Adam step: the update is lr * m_hat / (sqrt(v_hat) + eps), smooth in the gradient
-        assert float((p.detach().cpu() - rparams[n]).abs().max()) < 2e-5, n
+        # third Adam step: the update is lr * m_hat / (sqrt(v_hat) + eps), smooth in the gradient -- except where
+        # the gradient is pure rounding noise on both sides (the key bias of attention: its exact gradient is 0),
+        # there the update's sign is noise too, so those elements are only bounded by the step size
+        diff = (p.detach().cpu() - rparams[n].detach()).abs()
+        g = rparams[n].grad.abs()
+        sig = g > 1e-4 * g.max()
+        assert float(diff[sig].max()) < 2e-5, n
+        assert float(diff.max()) <= 2.1e-3, n
     # and back: what the trainer saves, the reference's strict loads accept (ViT entries in front)
     out = str(tmp_path / "resaved.pth")
     save_reference_checkpoint(out, model, tr, sched2, epoch=8, loss=float(loss.item()), metrics={"bleu4": 0.3},

@@ -3,6 +3,8 @@
 // shuffles, and written once.  Backward accumulates dgamma/dbeta partials in registers across a
 // grid-stride loop over rows and reduces them deterministically (fixed block count, fixed order).
 // See include/capdec.h (capdec_layernorm_fwd / _bwd).
+#include <mutex>
+
 #include "common.h"
 
 namespace capdec {
@@ -220,33 +222,107 @@ extern "C" int capdec_layernorm_fwd(const void* x, const void* gamma, const void
     return check_launch("capdec_layernorm_fwd");
 }
 
+// Shared launch plan of capdec_layernorm_bwd and capdec_layernorm_bwd_noalloc: `part` is the
+// [ln_blocks(M)][2][d] block of per-workgroup column partials (dgamma | dbeta), fully overwritten
+// by ln_bwd_kernel before ln_bwd_finalize_kernel reads it (nothing in it has to start at zero).
+static int ln_bwd_launch(const char* what, const void* dy, const void* x, const void* gamma, const void* beta,
+                         const void* mean, const void* rstd, void* dx, void* dx_drop, void* dgamma, void* dbeta, int M,
+                         int d, int act, float drop_p, uint64_t drop_seed, float drop2_p, uint64_t drop2_seed,
+                         float* part, hipStream_t st) {
+    const int nblk = ln_blocks(M);
+    const Dropout dr = make_dropout(drop_p, drop_seed), dr2 = make_dropout(drop2_p, drop2_seed);
+    const int nv = (d + 255) / 256;
+#define CALL(NV)                                                                                                     \
+    hipLaunchKernelGGL((ln_bwd_kernel<NV>), dim3(nblk), dim3(256), 0, st, (const float*)dy, (const float*)x,          \
+                       (const float*)gamma, (const float*)beta, (const float*)mean, (const float*)rstd, (float*)dx,   \
+                       (float*)dx_drop, part, M, d, act, dr, dr2)
+    if (nv <= 1) { CALL(1); } else if (nv <= 2) { CALL(2); } else if (nv <= 4) { CALL(4); } else { CALL(8); }
+#undef CALL
+    int rc = check_launch(what);
+    if (rc) return rc;
+    hipLaunchKernelGGL(ln_bwd_finalize_kernel, dim3((d + 15) / 16), dim3(256), 0, st, (const float*)part,
+                       (float*)dgamma, (float*)dbeta, nblk, d);
+    return check_launch(what);
+}
+
+static int ln_bwd_check(const char* what, const void* dy, const void* x, const void* gamma, const void* beta,
+                        const void* mean, const void* rstd, void* dx, void* dx_drop, void* dgamma, void* dbeta, int M,
+                        int d) {
+    CAPDEC_REQUIRE(dy && x && gamma && beta && mean && rstd && dx && dgamma && dbeta, "%s: null pointer", what);
+    CAPDEC_REQUIRE(M > 0 && d > 0 && d % 4 == 0 && d <= 2048, "%s: bad shape M=%d d=%d", what, M, d);
+    CAPDEC_REQUIRE(aligned16(x) && aligned16(dy) && aligned16(dx) && aligned16(gamma) && aligned16(beta) &&
+                       (!dx_drop || aligned16(dx_drop)), "%s: unaligned", what);
+    CAPDEC_REQUIRE((uint64_t)M * (uint64_t)d < (1ull << 32), "%s: M*d exceeds 2^32", what);
+    return CAPDEC_OK;
+}
+
 extern "C" int capdec_layernorm_bwd(const void* dy, const void* x, const void* gamma, const void* beta, const void* mean,
                                     const void* rstd, void* dx, void* dx_drop, void* dgamma, void* dbeta, int M, int d,
                                     int act, float drop_p, uint64_t drop_seed, float drop2_p, uint64_t drop2_seed,
                                     void* workspace, size_t workspace_bytes, capdec_stream_t stream) {
-    CAPDEC_REQUIRE(dy && x && gamma && beta && mean && rstd && dx && dgamma && dbeta, "capdec_layernorm_bwd: null pointer");
-    CAPDEC_REQUIRE(M > 0 && d > 0 && d % 4 == 0 && d <= 2048, "capdec_layernorm_bwd: bad shape M=%d d=%d", M, d);
-    CAPDEC_REQUIRE(aligned16(x) && aligned16(dy) && aligned16(dx) && aligned16(gamma) && aligned16(beta) &&
-                       (!dx_drop || aligned16(dx_drop)), "capdec_layernorm_bwd: unaligned");
-    CAPDEC_REQUIRE((uint64_t)M * (uint64_t)d < (1ull << 32), "capdec_layernorm_bwd: M*d exceeds 2^32");
-    const int nblk = ln_blocks(M);
-    const size_t need = (size_t)nblk * 2 * d * sizeof(float);
+    if (int rc = ln_bwd_check("capdec_layernorm_bwd", dy, x, gamma, beta, mean, rstd, dx, dx_drop, dgamma, dbeta, M, d))
+        return rc;
+    const size_t need = (size_t)ln_blocks(M) * 2 * d * sizeof(float);
     if (!workspace || workspace_bytes < need) {
         set_error("capdec_layernorm_bwd: needs %zu workspace bytes, got %zu", need, workspace_bytes);
         return CAPDEC_ERR_WORKSPACE;
     }
-    const Dropout dr = make_dropout(drop_p, drop_seed), dr2 = make_dropout(drop2_p, drop2_seed);
-    const int nv = (d + 255) / 256;
-    hipStream_t st = (hipStream_t)stream;
-#define CALL(NV)                                                                                                     \
-    hipLaunchKernelGGL((ln_bwd_kernel<NV>), dim3(nblk), dim3(256), 0, st, (const float*)dy, (const float*)x,          \
-                       (const float*)gamma, (const float*)beta, (const float*)mean, (const float*)rstd, (float*)dx,   \
-                       (float*)dx_drop, (float*)workspace, M, d, act, dr, dr2)
-    if (nv <= 1) { CALL(1); } else if (nv <= 2) { CALL(2); } else if (nv <= 4) { CALL(4); } else { CALL(8); }
-#undef CALL
-    int rc = check_launch("capdec_layernorm_bwd");
-    if (rc) return rc;
-    hipLaunchKernelGGL(ln_bwd_finalize_kernel, dim3((d + 15) / 16), dim3(256), 0, st, (const float*)workspace,
-                       (float*)dgamma, (float*)dbeta, nblk, d);
-    return check_launch("capdec_layernorm_bwd(finalize)");
+    return ln_bwd_launch("capdec_layernorm_bwd", dy, x, gamma, beta, mean, rstd, dx, dx_drop, dgamma, dbeta, M, d, act,
+                         drop_p, drop_seed, drop2_p, drop2_seed, (float*)workspace, (hipStream_t)stream);
+}
+
+// ---- the one entry point that allocates nothing (include/capdec.h: capdec_layernorm_bwd_noalloc) -------------
+// The column-partial block lives in a file-scope device array instead of a caller workspace.  `scratch` below is
+// only a host-side stand-in for that array: each GPU holds its own copy at its own address, looked up once per
+// device with hipGetSymbolAddress (first call on that device, with the device current) and kept in g_scratch[];
+// host code passes THAT pointer to the kernels, never the symbol.
+namespace capdec {
+constexpr size_t LN_NOALLOC_BYTES = CAPDEC_LN_NOALLOC_SCRATCH_BYTES;  // 4 MiB per GPU, held until the process ends
+static __device__ __align__(256) float scratch[LN_NOALLOC_BYTES / sizeof(float)];
+constexpr int LN_MAX_DEVICES = 64;
+static float* g_scratch[LN_MAX_DEVICES];  // per device; written once under g_scratch_mu
+static std::mutex g_scratch_mu;
+
+static int scratch_of_current_device(float** out) {
+    int dev = -1;
+    hipError_t e = hipGetDevice(&dev);
+    if (e != hipSuccess || dev < 0 || dev >= LN_MAX_DEVICES) {
+        set_error("capdec_layernorm_bwd_noalloc: hipGetDevice failed or device index %d >= %d (%s)", dev, LN_MAX_DEVICES,
+                  hipGetErrorString(e));
+        return CAPDEC_ERR_LAUNCH;
+    }
+    std::lock_guard<std::mutex> lock(g_scratch_mu);
+    if (!g_scratch[dev]) {
+        float* ptr = nullptr;
+        e = hipGetSymbolAddress((void**)&ptr, HIP_SYMBOL(scratch));
+        if (e != hipSuccess || !ptr) {
+            set_error("capdec_layernorm_bwd_noalloc: hipGetSymbolAddress(scratch) failed on device %d: %s", dev,
+                      hipGetErrorString(e));
+            return CAPDEC_ERR_LAUNCH;
+        }
+        g_scratch[dev] = ptr;
+    }
+    *out = g_scratch[dev];
+    return CAPDEC_OK;
+}
+}  // namespace capdec
+
+extern "C" size_t capdec_layernorm_bwd_noalloc_max_bytes(void) { return LN_NOALLOC_BYTES; }
+
+extern "C" int capdec_layernorm_bwd_noalloc(const void* dy, const void* x, const void* gamma, const void* beta,
+                                            const void* mean, const void* rstd, void* dx, void* dx_drop, void* dgamma,
+                                            void* dbeta, int M, int d, int act, float drop_p, uint64_t drop_seed,
+                                            float drop2_p, uint64_t drop2_seed, capdec_stream_t stream) {
+    const char* what = "capdec_layernorm_bwd_noalloc";
+    if (int rc = ln_bwd_check(what, dy, x, gamma, beta, mean, rstd, dx, dx_drop, dgamma, dbeta, M, d)) return rc;
+    const size_t need = (size_t)ln_blocks(M) * 2 * d * sizeof(float);
+    if (need > LN_NOALLOC_BYTES) {
+        set_error("%s: M=%d d=%d needs %zu bytes of column partials, the built-in scratch holds %zu "
+                  "(use capdec_layernorm_bwd with a caller workspace)", what, M, d, need, (size_t)LN_NOALLOC_BYTES);
+        return CAPDEC_ERR_WORKSPACE;
+    }
+    float* part = nullptr;
+    if (int rc = scratch_of_current_device(&part)) return rc;
+    return ln_bwd_launch(what, dy, x, gamma, beta, mean, rstd, dx, dx_drop, dgamma, dbeta, M, d, act, drop_p, drop_seed,
+                         drop2_p, drop2_seed, part, (hipStream_t)stream);
 }

@@ -92,6 +92,23 @@ int capdec_layernorm_bwd(const void* dy, const void* x, const void* gamma, const
                          int act, float drop_p, uint64_t drop_seed, float drop2_p, uint64_t drop2_seed,
                          void* workspace, size_t workspace_bytes, capdec_stream_t stream);
 
+/* capdec_layernorm_bwd_noalloc: capdec_layernorm_bwd for callers that CANNOT allocate or bring a workspace --
+ * code under HIP graph capture, tight serving / fine-tuning loops, harnesses that forbid hipMalloc.  It has NO
+ * counterpart in the reference (which never manages memory itself); same arguments minus the workspace, same
+ * kernels, same bits.  The per-workgroup column partials (dgamma | dbeta, ln_blocks(M) x 2 x d floats) go to a
+ * library-owned static device array of CAPDEC_LN_NOALLOC_SCRATCH_BYTES per GPU (held until the process ends;
+ * every C1-C3 shape fits: M any, d <= 1024).  Shapes that need more are rejected with CAPDEC_ERR_WORKSPACE.
+ * The call allocates nothing (no hipMalloc / hipFree; the array's per-device address is looked up on the
+ * first call on a device).  Every call on one GPU shares that GPU's array (it is fully overwritten before it is
+ * read, nothing has to be cleared): calls that overlap in time on the same GPU -- two streams, two threads --
+ * race; serialise them on one stream. */
+#define CAPDEC_LN_NOALLOC_SCRATCH_BYTES (4u << 20)
+size_t capdec_layernorm_bwd_noalloc_max_bytes(void);
+int capdec_layernorm_bwd_noalloc(const void* dy, const void* x, const void* gamma, const void* beta, const void* mean,
+                                 const void* rstd, void* dx, void* dx_drop, void* dgamma, void* dbeta, int M, int d,
+                                 int act, float drop_p, uint64_t drop_seed, float drop2_p, uint64_t drop2_seed,
+                                 capdec_stream_t stream);
+
 /* ---- token embedding + sinusoidal positions -----------------------------------------------------
  * fwd: out[b,t,:] = dropout(E[ids[b,t],:] + pe[t0+t,:]);  ids int64 [B,T]; pe [>=t0+T, d].
  * bwd: dE[v,:] = sum_{(b,t): ids=v} keep/(1-p) * dout[b,t,:]   (dE fully OVERWRITTEN, deterministic order).

@@ -19,7 +19,8 @@ _vp, _i, _f, _u64, _sz = C.c_void_p, C.c_int, C.c_float, C.c_uint64, C.c_size_t
 
 class Epilogue(C.Structure):
     _fields_ = [("bias", _vp), ("addend", _vp), ("pre", _vp), ("aux", _vp), ("colsum", _vp),
-                ("ld_addend", _i), ("act", _i), ("drop_p", _f), ("drop_seed", _u64)]
+                ("ld_addend", _i), ("act", _i), ("drop_p", _f), ("drop_seed", _u64),
+                ("ce_partials", _vp), ("ce_lse", _vp), ("ce_targets", _vp), ("ce_eps", _f), ("ce_grad_scale", _f)]
 
 
 # name -> (restype, argtypes); mirrors include/capdec.h one to one
@@ -28,6 +29,8 @@ SIGNATURES = {
     "capdec_last_error": (C.c_char_p, []),
     "capdec_gemm_workspace_bytes": (_sz, [_i, _i, _i]),
     "capdec_gemm_tune": (_i, [_i, _i, _i, _i]),
+    "capdec_gemm_plan_set": (_i, [_i, _i, _i, _i, _i, _i, _i, _i, _i, _i]),
+    "capdec_gemm_plan_clear": (None, []),
     "capdec_gemm": (_i, [_i, _i, _i, _i, _i, _vp, _i, _vp, _i, _vp, _i, C.POINTER(Epilogue), _i, _vp, _sz, _vp]),
     "capdec_layernorm_bwd_workspace_bytes": (_sz, [_i, _i]),
     "capdec_layernorm_fwd": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _f, _i, _f, _u64, _vp]),
@@ -45,6 +48,9 @@ SIGNATURES = {
     "capdec_attn_bwd": (_i, [_vp, _i, _vp, _i, _vp, _i, _vp, _i, _vp, _i, _vp, _vp, _vp, _i, _vp, _i, _vp, _i,
                              _i, _i, _i, _i, _i, _i, _f, _f, _u64, _vp]),
     "capdec_softmax_ce": (_i, [_vp, _i, _vp, _vp, _vp, _i, _i, _i, _f, _f, _vp]),
+    "capdec_gemm_ce_tiles": (_i, [_i, _i, _i, _i]),
+    "capdec_ce_finalize": (_i, [_vp, _i, _vp, _i, _vp, _vp, _vp, _i, _i, _f, _vp]),
+    "capdec_ce_dlogits": (_i, [_vp, _i, _vp, _vp, _i, _i, _f, _f, _vp]),
     "capdec_reduce_workspace_bytes": (_sz, []),
     "capdec_sum": (_i, [_vp, _sz, _f, _vp, _vp, _sz, _vp]),
     "capdec_sumsq": (_i, [_vp, _sz, _vp, _vp, _sz, _vp]),
@@ -110,11 +116,13 @@ def stream():
 _ws = {}
 
 
-def workspace(nbytes, device, tag="main"):
+def workspace(nbytes, device, tag="main", zero=False):
+    """``zero``: the buffer is zero-filled when (re)allocated -- capdec_gemm's split-K ticket words need that once
+    and keep themselves zero afterwards, so that buffer (tags "gemm:*") is never lent to any other op."""
     key = (device.type, device.index, tag)
     w = _ws.get(key)
     if w is None or w.numel() < nbytes:
         size = max(int(nbytes), 64 << 20)
-        w = torch.empty(size, dtype=torch.uint8, device=device)
+        w = (torch.zeros if zero else torch.empty)(size, dtype=torch.uint8, device=device)
         _ws[key] = w
     return w

@@ -32,6 +32,36 @@ struct AttnParams {
 
 __device__ __forceinline__ int row_of(int r, int half) { return (r & 3) + 8 * (r >> 2) + 4 * half; }
 
+// Workgroup -> (batch*head, tile).  One workgroup reads 256-byte head slices out of rows that hold all H heads side
+// by side; which XCD (and so which L2) serves a workgroup is blockIdx % 8 (round-robin dispatch).  With the natural
+// order, head h of every image lands on XCD h % 8 and each L2 / memory channel sees nothing but isolated 256-byte
+// pieces.  Here each XCD gets a CONTIGUOUS run of (b, h) items in its own dispatch order, so the H heads of one
+// image run on one XCD at about the same time and its L2 is asked for whole rows (speed only, never correctness).
+// Causal launches keep their longest-tiles-first order inside that run.
+__device__ __forceinline__ void attn_item(int n_bh, int n_tiles, bool longest_first, int& bh, int& tile) {
+    const int nb = n_bh * n_tiles;
+    int blk = blockIdx.x;
+    if (n_bh % 8 == 0) {
+        const int xcd = blk & 7, idx = blk >> 3, per = n_bh >> 3;  // per-XCD share of the (b, h) items
+        if (longest_first) {
+            tile = idx / per;
+            bh = xcd * per + idx % per;
+        } else {
+            tile = idx % n_tiles;
+            bh = xcd * per + idx / n_tiles;
+        }
+        return;
+    }
+    (void)nb;
+    if (longest_first) {
+        tile = blk / n_bh;
+        bh = blk % n_bh;
+    } else {
+        tile = blk % n_tiles;
+        bh = blk / n_tiles;
+    }
+}
+
 // A 32 x DH tile moves global -> registers (coalesced: 16 consecutive lanes read one 256-B row
 // piece) -> LDS, in two separate steps so the global loads of the NEXT tile can be in flight
 // while the current one is being multiplied (register prefetch, no extra LDS).
@@ -140,9 +170,9 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(DH <= 64 ? 3
     const int nqt = (p.Tq + 31) / 32;
     // causal: the tiles of one (b, h) differ in length (query tile i walks i + 1 key tiles), so the
     // longest ones are dispatched first and the short ones fill the tail of the launch
-    const int nbh = p.B * p.H;
-    const int qt = p.causal ? nqt - 1 - (int)blockIdx.x / nbh : (int)blockIdx.x % nqt;
-    const int bh = p.causal ? (int)blockIdx.x % nbh : (int)blockIdx.x / nqt;
+    int bh, qt;
+    attn_item(p.B * p.H, nqt, p.causal != 0, bh, qt);
+    if (p.causal) qt = nqt - 1 - qt;
     const int b = bh / p.H, h = bh % p.H;
     const int q0 = qt * 32, off = p.Tk - p.Tq;
     const float* qg = p.q + (size_t)b * p.Tq * p.ldq + h * DH;
@@ -241,9 +271,9 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2))) void at
     const int nqt = (p.Tq + 31) / 32;
     // causal: the tiles of one (b, h) differ in length (query tile i walks i + 1 key tiles), so the
     // longest ones are dispatched first and the short ones fill the tail of the launch
-    const int nbh = p.B * p.H;
-    const int qt = p.causal ? nqt - 1 - (int)blockIdx.x / nbh : (int)blockIdx.x % nqt;
-    const int bh = p.causal ? (int)blockIdx.x % nbh : (int)blockIdx.x / nqt;
+    int bh, qt;
+    attn_item(p.B * p.H, nqt, p.causal != 0, bh, qt);
+    if (p.causal) qt = nqt - 1 - qt;
     const int b = bh / p.H, h = bh % p.H;
     const int q0 = qt * 32, off = p.Tk - p.Tq;
     const int query = q0 + l31;
@@ -337,9 +367,8 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2))) void at
     __shared__ __attribute__((aligned(16))) float del_s[32];
     const int lane = threadIdx.x, l31 = lane & 31, half = lane >> 5;
     const int nkt = (p.Tk + 31) / 32;
-    const int nbh = p.B * p.H;  // causal: key tile 0 meets every query tile, the last one few -> longest first
-    const int kt = p.causal ? (int)blockIdx.x / nbh : (int)blockIdx.x % nkt;
-    const int bh = p.causal ? (int)blockIdx.x % nbh : (int)blockIdx.x / nkt;
+    int bh, kt;  // causal: key tile 0 meets every query tile, the last one few -> longest first
+    attn_item(p.B * p.H, nkt, p.causal != 0, bh, kt);
     const int b = bh / p.H, h = bh % p.H;
     const int k0 = kt * 32, off = p.Tk - p.Tq;
     const int key = k0 + l31;

@@ -14,7 +14,7 @@
 
 namespace capdec {
 
-typedef float f32x16 __attribute__((ext_vector_type(16)));
+
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
 
@@ -225,12 +225,12 @@ __global__ __launch_bounds__(256) void gemm_bf16_kernel(GemmParams p) {
         __syncthreads();
     }
 
-    const bool split = gridDim.z > 1;
-    if (do_colsum && tid < BM && m0 + tid < p.M) {
-        if (split) p.ws_colsum[(size_t)blockIdx.z * p.M + m0 + tid] = csum;
-        else p.colsum[m0 + tid] = csum;
-    }
-    float* wsz = split ? p.ws + (size_t)blockIdx.z * p.M * p.N : nullptr;
+    // split-K: only the last-arriving slice of this tile goes on, with the slice-ordered sum in acc / csum
+    if (gridDim.z > 1 && !splitk_combine<TM, TN>(p, acc, csum, do_colsum, tile_m * p.tiles_n + tile_n, m0, BM, tid,
+                                                  reinterpret_cast<int*>(smem)))
+        return;
+    if (do_colsum && tid < BM && m0 + tid < p.M) p.colsum[m0 + tid] = csum;
+    if (p.ce_part) ce_tile_partials<TM, TN, BM, BN>(p, acc, reinterpret_cast<float*>(smem), m0, n0, tile_n, tid);
 #pragma unroll
     for (int i = 0; i < TM; ++i)
 #pragma unroll
@@ -239,10 +239,7 @@ __global__ __launch_bounds__(256) void gemm_bf16_kernel(GemmParams p) {
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
                 const int m = m0 + wrow + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * half;
-                if (m < p.M && n < p.N) {
-                    if (split) wsz[(size_t)m * p.N + n] = acc[i][j][r];
-                    else p.C[(size_t)m * p.ldc + n] = epilogue_apply(p, acc[i][j][r], m, n);
-                }
+                if (m < p.M && n < p.N) p.C[(size_t)m * p.ldc + n] = epilogue_apply(p, acc[i][j][r], m, n);
             }
         }
 }
@@ -266,11 +263,11 @@ static void launch_bf16(const GemmParams& p, bool AK, bool BKM, bool vec, dim3 g
 
 // The bf16 product is operand-traffic bound (fp32 operands, 16x matrix rate): prefer the largest tile
 // that still gives every CU >= 2 workgroups; weight-gradient shapes (small output, long K) split K.
-GemmPlan plan_gemm_bf16(int M, int N, int K) {
-    if (g_gemm_force.bm) {
-        const int split = g_gemm_force.split > 0 ? g_gemm_force.split : 1;
+GemmPlan plan_gemm_bf16(int M, int N, int K, const GemmForce& force) {
+    if (force.bm) {
+        const int split = force.split > 0 ? force.split : 1;
         const int ks = cdiv(cdiv(K, split), HBK) * HBK;
-        const int bm = g_gemm_force.bm == 128 && g_gemm_force.bn == 128 ? 128 : 64;
+        const int bm = force.bm == 128 && force.bn == 128 ? 128 : 64;
         return GemmPlan{bm, bm, HBK, cdiv(K, ks), ks};
     }
     // calibrated on profiles/r01_gemm_sweep_bf16.txt: short-K products want many small workgroups

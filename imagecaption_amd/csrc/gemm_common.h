@@ -17,10 +17,99 @@ struct GemmParams {
     int ld_addend, act;
     Dropout drop;
     int ksplit;        // K elements per z-slice (multiple of the k-tile)
-    float* ws;         // [S][M][N] partial products when gridDim.z > 1
-    float* ws_colsum;  // [S][M]
+    // split-K (gridDim.z = S > 1), combined inside the launch by each tile's last-arriving slice (splitk_combine):
+    float* ws;         // [tile][S] slabs of BM*BN floats in the accumulator-register layout (float4 per thread)
+    float* ws_colsum;  // [S][m_pad] bias-gradient partials
+    int* counters;     // [tiles] arrival tickets; zero before the launch, reset to zero by the last arriver
+    int m_pad;         // tiles_m * BM
     int tiles_n;
+    // label-smoothed cross-entropy fused into the vocabulary projection (ref train.py:41-50):
+    float4* ce_part;        // forward: per (row, column tile) softmax partials (max, sum exp(z - max), sum z, -)
+    const float* ce_lse;    // backward: A holds the LOGITS; the A loaders turn them into dlogits on their way to LDS
+    const int64_t* ce_y;    //   dlogits[row, col] = gs * (exp(z - lse[row]) - eps/V - (1 - eps) * [col == y[row]])
+    float ce_gs, ce_u, ce_w;  // grad scale, eps / V, 1 - eps
 };
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+
+constexpr int GEMM_SPLITK_MAX_TILES = 4096;                       // arrival counters at the head of the workspace
+constexpr size_t GEMM_COUNTER_BYTES = GEMM_SPLITK_MAX_TILES * 4;  // 16 KiB
+
+// In-launch split-K combine, deterministic.  Every slice stores its partial accumulators to its slab WRITE-THROUGH
+// (sc1 stores, 16 B per lane, 4 KiB contiguous per store instruction: they leave the XCD's L2, so no release fence
+// and no L2 write-back is needed), drains them, and one lane takes a ticket; the slice that draws the last ticket
+// acquires (one agent-scope L1 invalidate), re-reads ALL S slabs (its own included) in slice order z = 0..S-1 --
+// so the sum's rounding does not depend on which slice happened to arrive last -- and returns true: that
+// workgroup alone runs the epilogue.  Placement-independent (correct wherever a tile's slices run); the ticket
+// word is reset by the last arriver, so it is zero again at the next launch (the caller zeroes it once, at
+// allocation).  `lds_flag`: one int of the kernel's own (now idle) LDS array.
+typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
+
+template <int TM, int TN>
+__device__ __forceinline__ bool splitk_combine(const GemmParams& p, f32x16 (&acc)[TM][TN], float& csum, bool do_colsum,
+                                               int tile_id, int m0, int bm, int tid, int* lds_flag) {
+    const int S = gridDim.z, z = blockIdx.z;
+    constexpr int PER = TM * TN * 4;  // float4 per thread per slab
+    float4* slab0 = reinterpret_cast<float4*>(p.ws) + (size_t)tile_id * S * (PER * 256);
+    float4* mine = slab0 + (size_t)z * (PER * 256);
+    const auto rsrc = __builtin_amdgcn_make_buffer_rsrc(mine, 0, PER * 256 * 16, 0x00020000);
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int j = 0; j < TN; ++j)
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                u32x4 v;
+                v.x = __float_as_uint(acc[i][j][4 * q]);
+                v.y = __float_as_uint(acc[i][j][4 * q + 1]);
+                v.z = __float_as_uint(acc[i][j][4 * q + 2]);
+                v.w = __float_as_uint(acc[i][j][4 * q + 3]);
+                __builtin_amdgcn_raw_buffer_store_b128(v, rsrc, (((i * TN + j) * 4 + q) * 256 + tid) * 16, 0, 16 /* sc1 */);
+            }
+    if (do_colsum && tid < bm)
+        __hip_atomic_store(&p.ws_colsum[(size_t)z * p.m_pad + m0 + tid], csum, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // every storing wave drains its write-through stores ...
+    __syncthreads();                                   // ... before one lane signals for all of them
+    if (tid == 0)
+        *lds_flag = __hip_atomic_fetch_add(&p.counters[tile_id], 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    __syncthreads();
+    if (*lds_flag != S - 1) return false;
+    if (tid == 0) {
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __hip_atomic_store(&p.counters[tile_id], 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+    __syncthreads();
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int j = 0; j < TN; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+    // about 8 float4 loads in flight per thread: the combine must fit in the registers of the main loop, or it
+    // would cost every workgroup of the launch (not only the last arrivers) its occupancy
+    constexpr int UNR = PER >= 8 ? 1 : 8 / PER;
+#pragma unroll UNR
+    for (int s = 0; s < S; ++s) {
+        const float4* sl = slab0 + (size_t)s * (PER * 256);
+#pragma unroll
+        for (int i = 0; i < TM; ++i)
+#pragma unroll
+            for (int j = 0; j < TN; ++j)
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    const float4 v = sl[((i * TN + j) * 4 + q) * 256 + tid];
+                    acc[i][j][4 * q] += v.x; acc[i][j][4 * q + 1] += v.y;
+                    acc[i][j][4 * q + 2] += v.z; acc[i][j][4 * q + 3] += v.w;
+                }
+    }
+    if (do_colsum && tid < bm) {
+        float t = 0.f;
+        for (int s = 0; s < S; ++s) t += p.ws_colsum[(size_t)s * p.m_pad + m0 + tid];
+        csum = t;
+    }
+    return true;
+}
 
 __device__ __forceinline__ float epilogue_apply(const GemmParams& p, float v, int m, int n) {
     if (p.bias) v += p.bias[n];
@@ -33,6 +122,75 @@ __device__ __forceinline__ float epilogue_apply(const GemmParams& p, float v, in
     return v;
 }
 
+// ---- fused cross-entropy pieces shared by the three GEMM kernels (same accumulator layout) ---------------------
+// Backward: four consecutive vocabulary columns col0.. of logits row `row` -> their loss gradients.  `nvalid`
+// components (and only if row_ok) are inside the matrix; the rest stay the zero padding the tile expects.
+__device__ __forceinline__ float4 ce_dlogits4(const GemmParams& p, float4 z, float lse, int y, int col0, int nvalid,
+                                              bool row_ok) {
+    float r[4] = {z.x, z.y, z.z, z.w};
+#pragma unroll
+    for (int c = 0; c < 4; ++c) {
+        float g = __expf(r[c] - lse) - p.ce_u;
+        if (col0 + c == y) g -= p.ce_w;
+        r[c] = (row_ok && c < nvalid) ? g * p.ce_gs : 0.f;
+    }
+    return make_float4(r[0], r[1], r[2], r[3]);
+}
+__device__ __forceinline__ int ce_target(const GemmParams& p, int row, int V) {
+    const int64_t y = p.ce_y[row];
+    return y < 0 ? 0 : (y >= V ? V - 1 : (int)y);  // out-of-range ids are clamped, as capdec_softmax_ce does
+}
+
+// Forward: per row of this workgroup's BM x BN logits tile (acc + bias), the softmax partials over the tile's
+// columns: (max, sum exp(z - max), sum z).  32 rows at a time go through LDS as [row][BN + 1] (written by the two
+// waves that own them in the accumulator layout), then 8 threads per row reduce BN / 8 columns each.  `lds`: the
+// kernel's own (idle) LDS array, >= 32 * (BN + 1) floats.
+template <int TM, int TN, int BM, int BN>
+__device__ __forceinline__ void ce_tile_partials(const GemmParams& p, const f32x16 (&acc)[TM][TN], float* lds, int m0,
+                                                 int n0, int tile_n, int tid) {
+    constexpr int LDR = BN + 1, CPT = BN / 8;
+    const int lane = tid & 63, wave = tid >> 6, l31 = lane & 31, half = lane >> 5;
+    const int wr = wave >> 1, wc = wave & 1;
+#pragma unroll
+    for (int c = 0; c < 2 * TM; ++c) {
+        const int cw = c / TM, ci = c % TM;
+        __syncthreads();
+        if (wr == cw) {
+#pragma unroll
+            for (int j = 0; j < TN; ++j) {
+                const int col = wc * (BN / 2) + j * 32 + l31;
+                const int n = n0 + col;
+                const float b = (p.bias && n < p.N) ? p.bias[n] : 0.f;
+#pragma unroll
+                for (int r = 0; r < 16; ++r) lds[((r & 3) + 8 * (r >> 2) + 4 * half) * LDR + col] = acc[ci][j][r] + b;
+            }
+        }
+        __syncthreads();
+        const int row = tid >> 3, part = tid & 7;
+        float v[CPT];
+        float mx = -INFINITY, sz = 0.f;
+#pragma unroll
+        for (int k = 0; k < CPT; ++k) {
+            const int col = part * CPT + k;
+            const bool ok = n0 + col < p.N;
+            v[k] = ok ? lds[row * LDR + col] : -INFINITY;
+            mx = fmaxf(mx, v[k]);
+            sz += ok ? v[k] : 0.f;
+        }
+        mx = fmaxf(mx, __shfl_xor(mx, 1, 64));
+        mx = fmaxf(mx, __shfl_xor(mx, 2, 64));
+        mx = fmaxf(mx, __shfl_xor(mx, 4, 64));
+        float se = 0.f;
+#pragma unroll
+        for (int k = 0; k < CPT; ++k) se += __expf(v[k] - mx);  // excluded columns: exp(-inf) = 0 (mx is finite: col 0 is in)
+        se += __shfl_xor(se, 1, 64); sz += __shfl_xor(sz, 1, 64);
+        se += __shfl_xor(se, 2, 64); sz += __shfl_xor(sz, 2, 64);
+        se += __shfl_xor(se, 4, 64); sz += __shfl_xor(sz, 4, 64);
+        const int m = m0 + cw * (BM / 2) + ci * 32 + row;
+        if (part == 0 && m < p.M) p.ce_part[(size_t)m * p.tiles_n + tile_n] = make_float4(mx, se, sz, 0.f);
+    }
+}
+
 struct GemmPlan {
     int bm, bn, bk, split, ksplit;
 };
@@ -43,9 +201,16 @@ extern GemmForce g_gemm_force;  // tuning hook (capdec_gemm_tune)
 
 static inline int cdiv(int a, int b) { return (a + b - 1) / b; }
 
-GemmPlan plan_gemm_bf16(int M, int N, int K);
+// workspace bytes of a split-K plan: ticket words, one slab per (tile, slice), bias-gradient partials
+static inline size_t splitk_workspace_bytes(const GemmPlan& pl, int M, int N) {
+    if (pl.split <= 1) return 0;
+    const size_t tiles_m = cdiv(M, pl.bm), tiles = tiles_m * cdiv(N, pl.bn);
+    return GEMM_COUNTER_BYTES + (tiles * pl.split * pl.bm * pl.bn + (size_t)pl.split * tiles_m * pl.bm) * sizeof(float);
+}
+
+GemmPlan plan_gemm_bf16(int M, int N, int K, const GemmForce& force);
 void launch_gemm_bf16(const GemmParams& p, const GemmPlan& pl, bool AK, bool BKM, bool vec, hipStream_t st);
-GemmPlan plan_gemm_f32x3(int M, int N, int K);
+GemmPlan plan_gemm_f32x3(int M, int N, int K, const GemmForce& force);
 int launch_gemm_f32x3(const GemmParams& p, const GemmPlan& pl, bool AK, bool BKM, bool vec, hipStream_t st);
 
 }  // namespace capdec

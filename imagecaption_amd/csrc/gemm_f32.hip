@@ -9,6 +9,10 @@
 //       rows padded by 2 float4 so the 8-lane ds_write_b128 groups and 16-lane ds_read_b128 groups
 //       hit distinct banks.
 //   row-contiguous operand (reduction index is the storage row): [k][row] -> four ds_read_b32.
+#include <mutex>
+#include <string>
+#include <unordered_map>
+
 #include "common.h"
 #include "gemm_common.h"
 
@@ -16,7 +20,22 @@ namespace capdec {
 
 GemmForce g_gemm_force = {0, 0, 0, 0};
 
-typedef float f32x16 __attribute__((ext_vector_type(16)));
+// Tuned plans (capdec_gemm_plan_set): what a caller measured to be the fastest (tile, split, k-tile) for one
+// product (transposes, shape, compute type) on the device it runs on.  A hit replaces the cost model's choice;
+// capdec_gemm_tune's process-wide force still comes first.
+static std::mutex g_plan_mu;
+static std::unordered_map<std::string, GemmForce> g_plans;
+static std::string plan_key(int ta, int tb, int M, int N, int K, int dtype) {
+    char buf[96];
+    snprintf(buf, sizeof(buf), "%d:%d:%d:%d:%d:%d", ta ? 1 : 0, tb ? 1 : 0, M, N, K, dtype);
+    return buf;
+}
+static GemmForce resolve_force(int ta, int tb, int M, int N, int K, int dtype) {
+    if (g_gemm_force.bm) return g_gemm_force;
+    std::lock_guard<std::mutex> lock(g_plan_mu);
+    auto it = g_plans.find(plan_key(ta, tb, M, N, K, dtype));
+    return it == g_plans.end() ? g_gemm_force : it->second;
+}
 
 template <bool VEC>
 __device__ __forceinline__ float4 load4(const float* ptr, bool ok, int rem) {
@@ -31,8 +50,18 @@ __device__ __forceinline__ float4 load4(const float* ptr, bool ok, int rem) {
 }
 
 // AK / BKM: operand is k-contiguous in memory (A stored [M,K]; B stored [N,K]).
-template <int BM, int BN, int GBK, bool AK, bool BKM, bool VEC>
-__global__ __launch_bounds__(256) void gemm_f32_kernel(GemmParams p) {
+// Register budget = the main loop's: the occupancy each tile shape reaches there (LDS- or register-bound) is
+// declared, so that the rarely executed split-K combine at the end is scheduled inside it instead of widening
+// the allocation of every workgroup.
+constexpr int gemm_f32_waves(int bm, int bn, int bk) {
+    return bm * bn == 64 * 64 ? (bk == 16 ? 8 : 4) : bm * bn == 128 * 64 ? (bk == 16 ? 5 : 3) : 1;
+}
+
+// CE: the A loaders read LOGITS and turn them into cross-entropy gradients on their way into LDS (see
+// gemm_common.h); a template flag so that the plain instantiations carry none of its registers.
+template <int BM, int BN, int GBK, bool AK, bool BKM, bool VEC, bool CE = false>
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(gemm_f32_waves(BM, BN, GBK))))
+void gemm_f32_kernel(GemmParams p) {
     constexpr int NT = 256;
     constexpr int TM = BM / 64, TN = BN / 64;  // 32x32 accumulators per wave in each direction
     constexpr int A_LD = AK ? (BM + 2) * 4 : (BM + 4);  // floats per k-quad (AK) or per k (row-contig)
@@ -96,6 +125,31 @@ __global__ __launch_bounds__(256) void gemm_f32_kernel(GemmParams p) {
     }
     const size_t step_a = AK ? (size_t)GBK : (size_t)GBK * p.lda;
     const size_t step_b = BKM ? (size_t)GBK : (size_t)GBK * p.ldb;
+    // fused cross-entropy backward (p.ce_lse != NULL): A holds logits.  Each float4 of A is four vocabulary columns
+    // of one logits row; its row's lse and target travel with it and the transform runs on the way into LDS.
+    constexpr bool ce = CE;
+    float ce_l[CE ? A_V4 : 1];
+    int ce_t[CE ? A_V4 : 1];
+    auto ce_fetch = [&](int k0) {  // AK: the row is this thread's for the whole K loop; else it is the k index
+#pragma unroll
+        for (int i = 0; i < (CE ? A_V4 : 0); ++i) {
+            const int f = tid + i * NT;
+            const int row = AK ? m0 + f / (GBK / 4) : k0 + f / (BM / 4);
+            const bool ok = AK ? row < p.M : row < kend;
+            ce_l[i] = ok ? p.ce_lse[row] : 0.f;
+            ce_t[i] = ok ? ce_target(p, row, AK ? p.K : p.M) : -1;
+        }
+    };
+    auto ce_apply = [&](int k0) {
+#pragma unroll
+        for (int i = 0; i < (CE ? A_V4 : 0); ++i) {
+            const int f = tid + i * NT;
+            const int row = AK ? m0 + f / (GBK / 4) : k0 + f / (BM / 4);
+            const int col0 = AK ? k0 + (f % (GBK / 4)) * 4 : m0 + (f % (BM / 4)) * 4;
+            const bool row_ok = AK ? row < p.M : row < kend;
+            ra[i] = ce_dlogits4(p, ra[i], ce_l[i], ce_t[i], col0, (AK ? kend : p.M) - col0, row_ok);
+        }
+    };
     auto gload_fast = [&]() {
 #pragma unroll
         for (int i = 0; i < A_V4; ++i) {
@@ -139,10 +193,12 @@ __global__ __launch_bounds__(256) void gemm_f32_kernel(GemmParams p) {
     auto gload = [&](int k0) {
         if (interior) gload_fast();
         else gload_guarded(k0);
+        if (!AK && ce) ce_fetch(k0);
     };
-    auto lstore = [&](int buf) {
+    auto lstore = [&](int buf, int k0) {
         float* As = smem + buf * (A_SZ + B_SZ);
         float* Bs = As + A_SZ;
+        if (ce) ce_apply(k0);
 #pragma unroll
         for (int i = 0; i < A_V4; ++i) {
             const int f = tid + i * NT;
@@ -178,9 +234,10 @@ __global__ __launch_bounds__(256) void gemm_f32_kernel(GemmParams p) {
     const bool do_colsum = (!AK) && p.colsum != nullptr && tile_n == 0;
     float csum = 0.f;
 
+    if (AK && ce) ce_fetch(kbeg);
     if (nk > 0) {
         gload(kbeg);
-        lstore(0);
+        lstore(0, kbeg);
     }
     __syncthreads();
     for (int kt = 0; kt < nk; ++kt) {
@@ -227,16 +284,16 @@ __global__ __launch_bounds__(256) void gemm_f32_kernel(GemmParams p) {
 #pragma unroll
             for (int k = 0; k < GBK; ++k) csum += As[k * A_LD + tid];
         }
-        if (kt + 1 < nk) lstore(buf ^ 1);
+        if (kt + 1 < nk) lstore(buf ^ 1, kbeg + (kt + 1) * GBK);
         __syncthreads();
     }
 
-    const bool split = gridDim.z > 1;
-    if (do_colsum && tid < BM && m0 + tid < p.M) {
-        if (split) p.ws_colsum[(size_t)blockIdx.z * p.M + m0 + tid] = csum;
-        else p.colsum[m0 + tid] = csum;
-    }
-    float* wsz = split ? p.ws + (size_t)blockIdx.z * p.M * p.N : nullptr;
+    // split-K: only the last-arriving slice of this tile goes on, with the slice-ordered sum in acc / csum
+    if (gridDim.z > 1 && !splitk_combine<TM, TN>(p, acc, csum, do_colsum, tile_m * p.tiles_n + tile_n, m0, BM, tid,
+                                                  reinterpret_cast<int*>(smem)))
+        return;
+    if (do_colsum && tid < BM && m0 + tid < p.M) p.colsum[m0 + tid] = csum;
+    if (p.ce_part) ce_tile_partials<TM, TN, BM, BN>(p, acc, smem, m0, n0, tile_n, tid);
 #pragma unroll
     for (int i = 0; i < TM; ++i)
 #pragma unroll
@@ -245,49 +302,9 @@ __global__ __launch_bounds__(256) void gemm_f32_kernel(GemmParams p) {
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
                 const int m = m0 + wrow + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * half;
-                if (m < p.M && n < p.N) {
-                    if (split) wsz[(size_t)m * p.N + n] = acc[i][j][r];
-                    else p.C[(size_t)m * p.ldc + n] = epilogue_apply(p, acc[i][j][r], m, n);
-                }
+                if (m < p.M && n < p.N) p.C[(size_t)m * p.ldc + n] = epilogue_apply(p, acc[i][j][r], m, n);
             }
         }
-}
-
-__global__ __launch_bounds__(256) void gemm_splitk_reduce_kernel(GemmParams p, int S, int vec) {
-    const size_t total = (size_t)p.M * p.N;
-    const size_t stride = (size_t)gridDim.x * blockDim.x;
-    if (vec) {  // N % 4 == 0: one float4 of every slab per thread, slabs summed in slab order
-        const size_t total4 = total >> 2;
-        for (size_t e4 = (size_t)blockIdx.x * blockDim.x + threadIdx.x; e4 < total4; e4 += stride) {
-            float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-#pragma unroll 4
-            for (int z = 0; z < S; ++z) {
-                const float4 t = reinterpret_cast<const float4*>(p.ws + (size_t)z * total)[e4];
-                v.x += t.x; v.y += t.y; v.z += t.z; v.w += t.w;
-            }
-            const size_t e = e4 << 2;
-            const int m = (int)(e / p.N), n = (int)(e % p.N);
-            float* c = p.C + (size_t)m * p.ldc + n;
-            c[0] = epilogue_apply(p, v.x, m, n);
-            c[1] = epilogue_apply(p, v.y, m, n + 1);
-            c[2] = epilogue_apply(p, v.z, m, n + 2);
-            c[3] = epilogue_apply(p, v.w, m, n + 3);
-        }
-    } else {
-        for (size_t e = (size_t)blockIdx.x * blockDim.x + threadIdx.x; e < total; e += stride) {
-            float v = 0.f;
-            for (int z = 0; z < S; ++z) v += p.ws[(size_t)z * total + e];
-            const int m = (int)(e / p.N), n = (int)(e % p.N);
-            p.C[(size_t)m * p.ldc + n] = epilogue_apply(p, v, m, n);
-        }
-    }
-    if (p.colsum && blockIdx.x == 0) {
-        for (int m = threadIdx.x; m < p.M; m += blockDim.x) {
-            float v = 0.f;
-            for (int z = 0; z < S; ++z) v += p.ws_colsum[(size_t)z * p.M + m];
-            p.colsum[m] = v;
-        }
-    }
 }
 
 // ---- host side: tile / split-K choice ---------------------------------------------------------
@@ -295,14 +312,14 @@ __global__ __launch_bounds__(256) void gemm_splitk_reduce_kernel(GemmParams p, i
 // with r co-resident workgroups runs r waves per SIMD; one wave per SIMD cannot cover its own
 // barrier / load stalls, so the matrix pipe's utilisation u(r) rises with r.  Cost = rounds of
 // workgroups per CU x work per workgroup / u, plus the split-K partial round trip.
-static GemmPlan plan_gemm(int M, int N, int K) {
+static GemmPlan plan_gemm(int M, int N, int K, const GemmForce& force) {
     static const int cand[4][2] = {{128, 128}, {128, 64}, {64, 128}, {64, 64}};
     static const double util[5] = {0.0, 0.55, 0.80, 0.97, 1.0};
-    const int bk = g_gemm_force.bk ? g_gemm_force.bk : 16;
-    if (g_gemm_force.bm) {
-        int split = g_gemm_force.split > 0 ? g_gemm_force.split : 1;
+    const int bk = force.bk ? force.bk : 16;
+    if (force.bm) {
+        int split = force.split > 0 ? force.split : 1;
         int ks = cdiv(cdiv(K, split), bk) * bk;
-        return GemmPlan{g_gemm_force.bm, g_gemm_force.bn, bk, cdiv(K, ks), ks};
+        return GemmPlan{force.bm, force.bn, bk, cdiv(K, ks), ks};
     }
     GemmPlan best{128, 128, bk, 1, K};
     double best_cost = 1e300;
@@ -332,6 +349,11 @@ static GemmPlan plan_gemm(int M, int N, int K) {
 
 template <int BM, int BN, int BK>
 static void launch_cfg(const GemmParams& p, bool AK, bool BKM, bool vec, dim3 grid, hipStream_t st) {
+    if (p.ce_lse) {  // the two backward products of the vocabulary projection: dlogits^T h and dlogits W (checked by the caller)
+        if (AK) hipLaunchKernelGGL((gemm_f32_kernel<BM, BN, BK, true, false, true, true>), grid, dim3(256), 0, st, p);
+        else hipLaunchKernelGGL((gemm_f32_kernel<BM, BN, BK, false, false, true, true>), grid, dim3(256), 0, st, p);
+        return;
+    }
 #define CAPDEC_LAUNCH(ak, bk, v) hipLaunchKernelGGL((gemm_f32_kernel<BM, BN, BK, ak, bk, v>), grid, dim3(256), 0, st, p)
     if (vec) {
         if (AK && BKM) CAPDEC_LAUNCH(true, true, true);
@@ -359,13 +381,52 @@ extern "C" int capdec_gemm_tune(int bm, int bn, int split, int bk) {
     return CAPDEC_OK;
 }
 
+// a plan whose tile count exceeds the ticket array runs unsplit (such shapes fill the chip without split-K anyway)
+static GemmPlan clamp_plan(GemmPlan pl, int M, int N, int K) {
+    if (pl.split > 1 && (long)cdiv(M, pl.bm) * cdiv(N, pl.bn) > GEMM_SPLITK_MAX_TILES) {
+        pl.split = 1;
+        pl.ksplit = K;
+    }
+    return pl;
+}
+
+static GemmPlan plan_for(int ta, int tb, int M, int N, int K, int dtype) {
+    const GemmForce f = resolve_force(ta, tb, M, N, K, dtype);
+    return dtype == CAPDEC_BF16 ? plan_gemm_bf16(M, N, K, f) : dtype == CAPDEC_F32X3 ? plan_gemm_f32x3(M, N, K, f)
+                                                                                      : plan_gemm(M, N, K, f);
+}
+
+extern "C" int capdec_gemm_ce_tiles(int M, int N, int K, int dtype) {
+    if (M <= 0 || N <= 0 || K <= 0) return 0;
+    return cdiv(N, plan_for(0, 1, M, N, K, dtype).bn);  // the logits product: A [M,K], B stored [N,K]
+}
+
+extern "C" int capdec_gemm_plan_set(int transA, int transB, int M, int N, int K, int dtype, int bm, int bn, int split,
+                                    int bk) {
+    const bool ok = bm == 0 || ((bm == 64 || bm == 128) && (bn == 64 || bn == 128) && split >= 1 && split <= 64 &&
+                                (bk == 0 || bk == 16 || bk == 32));
+    CAPDEC_REQUIRE(ok && M > 0 && N > 0 && K > 0, "capdec_gemm_plan_set: unsupported plan %dx%d split %d bk %d", bm, bn, split, bk);
+    std::lock_guard<std::mutex> lock(g_plan_mu);
+    if (bm == 0) g_plans.erase(plan_key(transA, transB, M, N, K, dtype));
+    else g_plans[plan_key(transA, transB, M, N, K, dtype)] = GemmForce{bm, bn, split, bk};
+    return CAPDEC_OK;
+}
+
+extern "C" void capdec_gemm_plan_clear(void) {
+    std::lock_guard<std::mutex> lock(g_plan_mu);
+    g_plans.clear();
+}
+
 extern "C" size_t capdec_gemm_workspace_bytes(int M, int N, int K) {
     if (M <= 0 || N <= 0 || K <= 0) return 0;
-    const GemmPlan a = plan_gemm(M, N, K), b = plan_gemm_bf16(M, N, K), c = plan_gemm_f32x3(M, N, K);
-    int split = a.split > b.split ? a.split : b.split;
-    if (c.split > split) split = c.split;
-    if (split <= 1) return 0;
-    return ((size_t)split * M * N + (size_t)split * M) * sizeof(float);
+    size_t need = 0;  // the largest need over both transposes of either operand and the three compute types
+    for (int ta = 0; ta < 2; ++ta)
+        for (int tb = 0; tb < 2; ++tb)
+            for (int dtype : {CAPDEC_F32, CAPDEC_BF16, CAPDEC_F32X3}) {
+                const size_t b = splitk_workspace_bytes(clamp_plan(plan_for(ta, tb, M, N, K, dtype), M, N, K), M, N);
+                if (b > need) need = b;
+            }
+    return need;
 }
 
 extern "C" int capdec_gemm(int transA, int transB, int M, int N, int K, const void* A, int lda, const void* B,
@@ -394,26 +455,49 @@ extern "C" int capdec_gemm(int transA, int transB, int M, int N, int K, const vo
         p.ld_addend = ep->ld_addend;
         p.act = ep->act;
         p.drop = make_dropout(ep->drop_p, ep->drop_seed);
+        p.ce_part = (float4*)ep->ce_partials;
+        p.ce_lse = (const float*)ep->ce_lse;
+        p.ce_y = ep->ce_targets;
+        if (p.ce_lse) {
+            const int V = transA ? M : K;  // A is the [rows, V] logits block either way
+            CAPDEC_REQUIRE(ep->ce_targets && dtype == CAPDEC_F32 && ep->ce_eps >= 0.f && ep->ce_eps < 1.f,
+                           "capdec_gemm: ce_lse needs ce_targets, 0 <= ce_eps < 1 and dtype CAPDEC_F32 "
+                           "(other compute types: capdec_ce_dlogits, then a plain product)");
+            p.ce_gs = ep->ce_grad_scale;
+            p.ce_u = ep->ce_eps / (float)V;
+            p.ce_w = 1.f - ep->ce_eps;
+        }
+        CAPDEC_REQUIRE(!p.ce_part || (!transA && aligned16(ep->ce_partials) && ep->act == CAPDEC_ACT_NONE &&
+                                      !ep->addend && ep->drop_p == 0.f),
+                       "capdec_gemm: ce_partials is for the plain logits product (A not transposed, bias only)");
         CAPDEC_REQUIRE(ep->act != CAPDEC_ACT_GELU_BWD || ep->aux, "capdec_gemm: ACT_GELU_BWD needs aux");
         CAPDEC_REQUIRE(!ep->colsum || transA, "capdec_gemm: colsum needs transA=1");
         CAPDEC_REQUIRE(!ep->addend || ep->ld_addend >= N, "capdec_gemm: ld_addend too small");
         CAPDEC_REQUIRE(ep->drop_p >= 0.f && ep->drop_p < 1.f, "capdec_gemm: drop_p out of range");
     }
-    GemmPlan pl = dtype == CAPDEC_BF16 ? plan_gemm_bf16(M, N, K)
-                  : dtype == CAPDEC_F32X3 ? plan_gemm_f32x3(M, N, K) : plan_gemm(M, N, K);
+    GemmPlan pl = clamp_plan(plan_for(transA, transB, M, N, K, dtype), M, N, K);
+    if (p.ce_part) {  // a row's partials come from whole column tiles: no K split (the vocabulary product has none)
+        pl.split = 1;
+        pl.ksplit = K;
+    }
     if (pl.split > 1) {
-        const size_t need = ((size_t)pl.split * M * N + (size_t)pl.split * M) * sizeof(float);
-        if (!workspace || workspace_bytes < need) {
-            set_error("capdec_gemm: split-K needs %zu workspace bytes, got %zu", need, workspace_bytes);
+        const size_t need = splitk_workspace_bytes(pl, M, N);
+        if (!workspace || workspace_bytes < need || !aligned16(workspace)) {
+            set_error("capdec_gemm: split-K needs %zu workspace bytes (16-byte aligned), got %zu", need, workspace_bytes);
             return CAPDEC_ERR_WORKSPACE;
         }
-        p.ws = (float*)workspace;
-        p.ws_colsum = p.ws + (size_t)pl.split * M * N;
+        const size_t tiles_m = cdiv(M, pl.bm), tiles = tiles_m * cdiv(N, pl.bn);
+        p.counters = (int*)workspace;
+        p.ws = (float*)((char*)workspace + GEMM_COUNTER_BYTES);
+        p.ws_colsum = p.ws + tiles * pl.split * pl.bm * pl.bn;
+        p.m_pad = (int)tiles_m * pl.bm;
     }
     p.ksplit = pl.ksplit;
     p.tiles_n = cdiv(N, pl.bn);
     const bool vec = aligned16(A) && aligned16(B) && (lda % 4 == 0) && (ldb % 4 == 0);
     const bool AK = !transA, BKM = transB != 0;
+    CAPDEC_REQUIRE(!p.ce_lse || (vec && !BKM), "capdec_gemm: ce_lse needs transB = 0 and 16-byte aligned operands with "
+                                               "leading dimensions that are multiples of 4");
     dim3 grid(cdiv(M, pl.bm) * p.tiles_n, 1, pl.split);
     hipStream_t st = (hipStream_t)stream;
     if (dtype == CAPDEC_BF16) {
@@ -432,16 +516,5 @@ extern "C" int capdec_gemm(int transA, int transB, int M, int N, int K, const vo
         else if (pl.bm == 64 && pl.bn == 128) launch_cfg<64, 128, 16>(p, AK, BKM, vec, grid, st);
         else launch_cfg<64, 64, 16>(p, AK, BKM, vec, grid, st);
     }
-    int rc = check_launch("capdec_gemm");
-    if (rc) return rc;
-    if (pl.split > 1) {
-        const size_t total = (size_t)M * N;
-        const int vec4 = (N % 4 == 0) && aligned16(workspace) ? 1 : 0;
-        int blocks = (int)(((vec4 ? total / 4 : total) + 255) / 256);
-        if (blocks > 2048) blocks = 2048;
-        if (blocks < 1) blocks = 1;
-        hipLaunchKernelGGL(gemm_splitk_reduce_kernel, dim3(blocks), dim3(256), 0, st, p, pl.split, vec4);
-        rc = check_launch("capdec_gemm(split-K reduce)");
-    }
-    return rc;
+    return check_launch("capdec_gemm");
 }

@@ -31,7 +31,7 @@
 
 namespace capdec {
 
-typedef float f32x16 __attribute__((ext_vector_type(16)));
+
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
@@ -234,12 +234,16 @@ void gemm_f32x3_kernel(GemmParams p) {
         __syncthreads();
     }
 
-    const bool split = gridDim.z > 1;
-    if (do_colsum && tid < BM && m0 + tid < p.M) {
-        if (split) p.ws_colsum[(size_t)blockIdx.z * p.M + m0 + tid] = csum;
-        else p.colsum[m0 + tid] = csum;
-    }
-    float* wsz = split ? p.ws + (size_t)blockIdx.z * p.M * p.N : nullptr;
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int j = 0; j < TN; ++j) acc[i][j] += cor[i][j];  // main term + the five corrections
+    // split-K: only the last-arriving slice of this tile goes on, with the slice-ordered sum in acc / csum
+    if (gridDim.z > 1 && !splitk_combine<TM, TN>(p, acc, csum, do_colsum, tile_m * p.tiles_n + tile_n, m0, BM, tid,
+                                                  reinterpret_cast<int*>(x3_smem)))
+        return;
+    if (do_colsum && tid < BM && m0 + tid < p.M) p.colsum[m0 + tid] = csum;
+    if (p.ce_part) ce_tile_partials<TM, TN, BM, BN>(p, acc, reinterpret_cast<float*>(x3_smem), m0, n0, tile_n, tid);
 #pragma unroll
     for (int i = 0; i < TM; ++i)
 #pragma unroll
@@ -248,11 +252,7 @@ void gemm_f32x3_kernel(GemmParams p) {
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
                 const int m = m0 + wrow + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * half;
-                if (m < p.M && n < p.N) {
-                    const float v = acc[i][j][r] + cor[i][j][r];
-                    if (split) wsz[(size_t)m * p.N + n] = v;
-                    else p.C[(size_t)m * p.ldc + n] = epilogue_apply(p, v, m, n);
-                }
+                if (m < p.M && n < p.N) p.C[(size_t)m * p.ldc + n] = epilogue_apply(p, acc[i][j][r], m, n);
             }
         }
 }
@@ -292,11 +292,11 @@ static int launch_x3(const GemmParams& p, bool AK, bool BKM, bool vec, dim3 grid
 #undef CAPDEC_LAUNCH
 }
 
-GemmPlan plan_gemm_f32x3(int M, int N, int K) {
-    if (g_gemm_force.bm) {
-        const int split = g_gemm_force.split > 0 ? g_gemm_force.split : 1;
+GemmPlan plan_gemm_f32x3(int M, int N, int K, const GemmForce& force) {
+    if (force.bm) {
+        const int split = force.split > 0 ? force.split : 1;
         const int ks = cdiv(cdiv(K, split), XBK) * XBK;
-        int bm = g_gemm_force.bm, bn = g_gemm_force.bn;
+        int bm = force.bm, bn = force.bn;
         if (bm == 64 && bn == 128) bm = 128, bn = 64;  // not instantiated; nearest
         return GemmPlan{bm, bn, XBK, cdiv(K, ks), ks};
     }

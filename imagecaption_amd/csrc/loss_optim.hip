@@ -59,6 +59,52 @@ __global__ __launch_bounds__(256) void softmax_ce_kernel(const float* logits, in
     }
 }
 
+// ---- fused form: the vocabulary product's epilogue left per-tile partials (gemm_common.h: ce_tile_partials) ----
+// One wave per row: combine (max, sum exp, sum z) over the row's column tiles in a fixed order.
+__global__ __launch_bounds__(256) void ce_finalize_kernel(const float4* __restrict__ part, int tiles,
+                                                           const float* __restrict__ logits, int ldl,
+                                                           const int64_t* __restrict__ targets, float* __restrict__ lse_out,
+                                                           float* __restrict__ loss_rows, int M, int V, float eps) {
+    const int lane = threadIdx.x & 63;
+    const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (row >= M) return;
+    const float4* pr = part + (size_t)row * tiles;
+    float mx = -INFINITY;
+    for (int t = lane; t < tiles; t += 64) mx = fmaxf(mx, pr[t].x);
+    mx = wave_max(mx);
+    float se = 0.f, sz = 0.f;
+    for (int t = lane; t < tiles; t += 64) {
+        const float4 q = pr[t];
+        se += q.y * __expf(q.x - mx);
+        sz += q.z;
+    }
+    se = wave_sum(se);
+    sz = wave_sum(sz);
+    if (lane == 0) {
+        const float lse = mx + __logf(se);
+        int64_t y = targets[row];
+        y = y < 0 ? 0 : (y >= V ? V - 1 : y);
+        if (lse_out) lse_out[row] = lse;
+        if (loss_rows) loss_rows[row] = lse - (1.f - eps) * logits[(size_t)row * ldl + y] - (eps / (float)V) * sz;
+    }
+}
+
+// dlogits in place from the logits and the row lse (one read, one write)
+__global__ __launch_bounds__(256) void ce_dlogits_kernel(float* z, int ldl, const float* __restrict__ lse_in,
+                                                          const int64_t* __restrict__ targets, int V, float eps,
+                                                          float grad_scale) {
+    const int m = blockIdx.x;
+    float* zr = z + (size_t)m * ldl;
+    const float lse = lse_in[m], u = eps / (float)V;
+    int64_t y = targets[m];
+    y = y < 0 ? 0 : (y >= V ? V - 1 : y);
+    for (int v = threadIdx.x; v < V; v += 256) {
+        float g = __expf(zr[v] - lse) - u;
+        if (v == (int)y) g -= (1.f - eps);
+        zr[v] = g * grad_scale;
+    }
+}
+
 // ---- deterministic reductions: 1024 fixed partials, then one block ---------------------------
 constexpr int RED_PARTS = 1024;
 
@@ -131,6 +177,24 @@ extern "C" int capdec_softmax_ce(const void* logits, int ldl, const int64_t* tar
     hipLaunchKernelGGL(softmax_ce_kernel, dim3(M), dim3(256), 0, (hipStream_t)stream, (const float*)logits, ldl, targets,
                        (float*)loss_rows, (float*)dlogits, lddl, V, eps, grad_scale);
     return check_launch("capdec_softmax_ce");
+}
+
+extern "C" int capdec_ce_finalize(const void* partials, int tiles, const void* logits, int ldl, const int64_t* targets,
+                                  void* lse, void* loss_rows, int M, int V, float eps, capdec_stream_t stream) {
+    CAPDEC_REQUIRE(partials && logits && targets && (lse || loss_rows), "capdec_ce_finalize: null pointer");
+    CAPDEC_REQUIRE(M > 0 && V > 0 && tiles > 0 && ldl >= V && aligned16(partials), "capdec_ce_finalize: bad shape M=%d V=%d "
+                   "tiles=%d (partials must be 16-byte aligned)", M, V, tiles);
+    hipLaunchKernelGGL(ce_finalize_kernel, dim3((M + 3) / 4), dim3(256), 0, (hipStream_t)stream, (const float4*)partials,
+                       tiles, (const float*)logits, ldl, targets, (float*)lse, (float*)loss_rows, M, V, eps);
+    return check_launch("capdec_ce_finalize");
+}
+
+extern "C" int capdec_ce_dlogits(void* logits, int ldl, const void* lse, const int64_t* targets, int M, int V, float eps,
+                                 float grad_scale, capdec_stream_t stream) {
+    CAPDEC_REQUIRE(logits && lse && targets && M > 0 && V > 0 && ldl >= V, "capdec_ce_dlogits: bad arguments");
+    hipLaunchKernelGGL(ce_dlogits_kernel, dim3(M), dim3(256), 0, (hipStream_t)stream, (float*)logits, ldl, (const float*)lse,
+                       targets, V, eps, grad_scale);
+    return check_launch("capdec_ce_dlogits");
 }
 
 extern "C" size_t capdec_reduce_workspace_bytes(void) { return RED_PARTS * sizeof(float); }

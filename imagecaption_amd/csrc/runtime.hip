@@ -25,5 +25,5 @@ int check_launch(const char* what) {
 
 }  // namespace capdec
 
-extern "C" int capdec_abi_version(void) { return 1; }
+extern "C" int capdec_abi_version(void) { return 2; }  // 2: capdec_epilogue.ce_*, split-K tickets in the workspace
 extern "C" const char* capdec_last_error(void) { return capdec::g_err; }

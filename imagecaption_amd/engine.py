@@ -253,19 +253,23 @@ def proj_bwd(P, G, sv, dmem, dp, want_df=False):
     return ops.linear_dgrad(g1, P["0.weight"]) if want_df else None
 
 
-def head_fwd(P, x, dp, save, logits_out=None):
-    """output_layer (ref models.py:68-73): Linear, GELU, Dropout, Linear on x [M,d] -> logits [M,V]."""
+def head_fwd(P, x, dp, save, logits_out=None, ce_partials=None):
+    """output_layer (ref models.py:68-73): Linear, GELU, Dropout, Linear on x [M,d] -> logits [M,V].
+    ``ce_partials``: the vocabulary product's epilogue also leaves the per-tile softmax partials of its logits there
+    (label-smoothed cross-entropy fused into the product, ref train.py:41-50)."""
     u = torch.empty((x.shape[0], P["0.weight"].shape[0]), dtype=torch.float32, device=x.device) \
         if save is not None else None
     h = ops.linear_fwd(x, P["0.weight"], P["0.bias"], act=ACT_GELU, pre=u, drop_p=dp.p, seed=dp.seed(S_HEAD))
-    logits = ops.linear_fwd(h, P["3.weight"], P["3.bias"], out=logits_out)
+    logits = ops.linear_fwd(h, P["3.weight"], P["3.bias"], out=logits_out, ce_partials=ce_partials)
     if save is not None:
         save.update(x=x, u=u, h=h)
     return logits
 
 
-def head_bwd(P, G, sv, dlogits, dp):
-    ops.linear_wgrad(dlogits, sv["h"], dw=G["3.weight"], db=G["3.bias"])
-    du = ops.linear_dgrad(dlogits, P["3.weight"], gelu_pre=sv["u"], drop_p=dp.p, seed=dp.seed(S_HEAD))
+def head_bwd(P, G, sv, dlogits, dp, ce=None):
+    """``ce = (lse, targets, eps, grad_scale)``: ``dlogits`` is still the LOGITS block; both products read it through
+    the cross-entropy gradient transform in their loaders (nothing is written back to the block)."""
+    ops.linear_wgrad(dlogits, sv["h"], dw=G["3.weight"], db=G["3.bias"], ce=ce)
+    du = ops.linear_dgrad(dlogits, P["3.weight"], gelu_pre=sv["u"], drop_p=dp.p, seed=dp.seed(S_HEAD), ce=ce)
     ops.linear_wgrad(du, sv["x"], dw=G["0.weight"], db=G["0.bias"])
     return ops.linear_dgrad(du, P["0.weight"])

@@ -14,7 +14,7 @@ from . import _capi
 from ._capi import ACT_GELU_BWD, ACT_NONE, F32, check, lib, ptr, stream
 
 __all__ = ["compute_dtype", "gemm", "linear_fwd", "linear_dgrad", "linear_wgrad", "layernorm_fwd", "layernorm_bwd", "embed_fwd",
-           "embed_bwd", "attn_fwd", "attn_bwd", "softmax_ce", "reduce_sum", "sumsq", "adamw", "clip_scale", "pe_add",
+           "embed_bwd", "attn_fwd", "attn_bwd", "softmax_ce", "ce_tiles", "ce_finalize", "ce_dlogits", "reduce_sum", "sumsq", "adamw", "clip_scale", "pe_add",
            "act_dropout_bwd"]
 
 
@@ -176,10 +176,95 @@ def _mat(t, name):
 
 _WS_NEED = {}  # (M, N, K) -> capdec_gemm_workspace_bytes, asked once per shape
 
+# ---- measured GEMM plans ------------------------------------------------------------------------------------
+# The library's cost model picks a (tile, split-K, k-tile) plan per shape; what is really fastest depends on how a
+# shape's tiles fall on 256 CUs x 8 XCDs, so callers with a fixed set of shapes (a training step, a decode loop)
+# can MEASURE instead: record the products of one pass (``TUNE_RECORD``), time every candidate plan of each on
+# synthetic operands of the same geometry (outside any timed region), and pin the winners in the library
+# (capdec_gemm_plan_set).  A plan changes speed and the rounding order of the K sum, nothing else.
+TUNE_RECORD = None  # dict while recording: (trans_a, trans_b, M, N, K, dtype) -> (lda, ldb, ldc, reads logits as dlogits)
+_TUNED = {}         # the same key -> (bm, bn, split, bk) already pinned in this process
+
+
+def _plan_candidates(dtype, M, N, K):
+    tiles_by = {F32: [(128, 128), (128, 64), (64, 128), (64, 64)], _capi.BF16: [(128, 128), (64, 64)],
+                _capi.F32X3: [(128, 128), (128, 64), (64, 64)]}[dtype]
+    bks = (16, 32) if dtype == F32 else (0,)
+    for bm, bn in tiles_by:
+        tiles = -(-M // bm) * -(-N // bn)
+        for split in (1, 2, 3, 4, 5, 6, 8, 12, 16):
+            if split > 1 and (K // split < 128 or tiles > 4096 or tiles * split > 4096):
+                continue  # a chip-filling grid gains nothing from K slices; the ticket array holds 4096 tiles
+            for bk in bks:
+                yield bm, bn, split, bk
+
+
+def tune_gemm_plans(signatures, reps=4, min_gain=0.03, verbose=False):
+    """Time every candidate plan of every recorded product and pin the fastest (if it beats the cost model's own
+    choice by ``min_gain``).  ``signatures``: the dict ``TUNE_RECORD`` collected.  Returns {key: (plan, us, us_default)}."""
+    global COMPUTE_DTYPE
+    l = lib()
+    out = {}
+    saved = COMPUTE_DTYPE
+
+    def timed(fn):
+        fn()
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        for _ in range(reps):
+            fn()
+        e1.record()
+        e1.synchronize()
+        return e0.elapsed_time(e1) / reps * 1e3
+
+    try:
+        for key, (lda, ldb, ldc, has_ce) in sorted(signatures.items()):
+            if key in _TUNED:
+                continue
+            ta, tb, M, N, K, dtype = key
+            dev = torch.device("cuda", torch.cuda.current_device())
+            a = torch.randn((K if ta else M, lda), device=dev)[:, :(M if ta else K)]
+            b = torch.randn((N if tb else K, ldb), device=dev)[:, :(K if tb else N)]
+            c = torch.empty((M, ldc), device=dev)[:, :N]
+            ce = None
+            if has_ce:  # the loaders that turn logits into dlogits are their own instantiation: time THAT kernel
+                rows, V = a.shape
+                ce = (torch.full((rows,), math.log(V), device=dev), torch.randint(0, V, (rows,), device=dev), 0.1, 1.0 / rows)
+            COMPUTE_DTYPE = dtype
+            check(l.capdec_gemm_tune(0, 0, 0, 0), "capdec_gemm_tune")
+            _WS_NEED.clear()
+            t_default = timed(lambda: gemm(a, b, ta, tb, out=c, ce=ce))
+            best = (None, t_default)
+            for bm, bn, split, bk in _plan_candidates(dtype, M, N, K):
+                check(l.capdec_gemm_tune(bm, bn, split, bk), "capdec_gemm_tune")
+                _WS_NEED.clear()  # the workspace need follows the forced plan
+                t = timed(lambda: gemm(a, b, ta, tb, out=c, ce=ce))
+                if t < best[1]:
+                    best = ((bm, bn, split, bk), t)
+            check(l.capdec_gemm_tune(0, 0, 0, 0), "capdec_gemm_tune")
+            if best[0] is not None and best[1] < (1.0 - min_gain) * t_default:
+                check(l.capdec_gemm_plan_set(ta, tb, M, N, K, dtype, *best[0]), "capdec_gemm_plan_set")
+                _TUNED[key] = best[0]
+            else:
+                _TUNED[key] = None
+            out[key] = (_TUNED[key], best[1], t_default)
+            if verbose:
+                print(f"[capdec tune] {'nt'[ta]}{'nt'[tb]} {M}x{N}x{K} dtype {dtype}: default {t_default:7.1f} us -> "
+                      f"{best[0]} {best[1]:7.1f} us", file=sys.stderr, flush=True)
+    finally:
+        COMPUTE_DTYPE = saved
+        l.capdec_gemm_tune(0, 0, 0, 0)
+        _WS_NEED.clear()
+    return out
+
 
 def gemm(a, b, trans_a, trans_b, out=None, bias=None, addend=None, pre=None, aux=None, colsum=None, act=ACT_NONE,
-         drop_p=0.0, seed=0):
-    """out[M,N] = epilogue(op(a) @ op(b)); see capdec_gemm in include/capdec.h."""
+         drop_p=0.0, seed=0, ce_partials=None, ce=None):
+    """out[M,N] = epilogue(op(a) @ op(b)); see capdec_gemm in include/capdec.h.
+
+    ``ce_partials``: [M, ce_tiles(M, N, K)] x 4 floats receiving the per-tile softmax partials of the logits this
+    product writes (fused cross-entropy, forward).  ``ce = (lse, targets, eps, grad_scale)``: ``a`` holds LOGITS and
+    is read as dlogits (fused cross-entropy, backward; exact-fp32 compute type only)."""
     _mat(a, "gemm.a"), _mat(b, "gemm.b")
     M, K = (a.shape[1], a.shape[0]) if trans_a else (a.shape[0], a.shape[1])
     Kb, N = (b.shape[1], b.shape[0]) if trans_b else (b.shape[0], b.shape[1])
@@ -190,6 +275,9 @@ def gemm(a, b, trans_a, trans_b, out=None, bias=None, addend=None, pre=None, aux
     _mat(out, "gemm.out")
     if tuple(out.shape) != (M, N):
         raise _capi.CapdecError(f"gemm: out is {tuple(out.shape)}, expected {(M, N)}")
+    if TUNE_RECORD is not None:
+        TUNE_RECORD.setdefault((int(trans_a), int(trans_b), M, N, K, COMPUTE_DTYPE),
+                               (a.stride(0), b.stride(0), out.stride(0), ce is not None))
     ep = _capi.Epilogue()
     ep.bias, ep.addend, ep.pre, ep.aux, ep.colsum = ptr(bias), ptr(addend), ptr(pre), ptr(aux), ptr(colsum)
     ep.ld_addend = addend.stride(0) if addend is not None else 0
@@ -204,10 +292,22 @@ def gemm(a, b, trans_a, trans_b, out=None, bias=None, addend=None, pre=None, aux
         raise _capi.CapdecError("gemm: colsum must have M elements")
     ep.act, ep.drop_p, ep.drop_seed = act, float(drop_p), int(seed) & 0xFFFFFFFFFFFFFFFF
     l = lib()
+    if ce_partials is not None:
+        tiles = l.capdec_gemm_ce_tiles(M, N, K, COMPUTE_DTYPE)
+        if tuple(ce_partials.shape) != (M, tiles, 4) or not ce_partials.is_contiguous():
+            raise _capi.CapdecError(f"gemm: ce_partials must be a contiguous [M, {tiles}, 4] tensor")
+        ep.ce_partials = ptr(_req(ce_partials, "gemm.ce_partials"))
+    if ce is not None:
+        lse, targets, eps, gs = ce
+        rows = a.shape[0]
+        if _req(lse, "gemm.ce.lse").numel() != rows or _req(targets, "gemm.ce.targets", torch.int64).numel() != rows \
+                or not (lse.is_contiguous() and targets.is_contiguous()):
+            raise _capi.CapdecError("gemm: ce needs contiguous lse / targets with one entry per row of the logits block")
+        ep.ce_lse, ep.ce_targets, ep.ce_eps, ep.ce_grad_scale = ptr(lse), ptr(targets), float(eps), float(gs)
     need = _WS_NEED.get((M, N, K))
     if need is None:
         need = _WS_NEED[(M, N, K)] = l.capdec_gemm_workspace_bytes(M, N, K)
-    ws = _capi.workspace(need, a.device, _WS_TAG) if need else None
+    ws = _capi.workspace(need, a.device, "gemm:" + _WS_TAG, zero=True) if need else None
     args = (int(trans_a), int(trans_b), M, N, K, ptr(a), a.stride(0), ptr(b), b.stride(0), ptr(out), out.stride(0),
             C.byref(ep), COMPUTE_DTYPE, ptr(ws), ws.numel() if ws is not None else 0, stream())
     if PROFILE is None:  # the common case: no per-launch events, no label formatting
@@ -218,26 +318,27 @@ def gemm(a, b, trans_a, trans_b, out=None, bias=None, addend=None, pre=None, aux
     return out
 
 
-def linear_fwd(x, w, bias=None, out=None, act=ACT_NONE, pre=None, drop_p=0.0, seed=0, addend=None):
+def linear_fwd(x, w, bias=None, out=None, act=ACT_NONE, pre=None, drop_p=0.0, seed=0, addend=None, ce_partials=None):
     """y = addend + dropout(act(x @ w.T + bias)); x [M,K], w [N,K]."""
-    return gemm(x, w, False, True, out=out, bias=bias, addend=addend, pre=pre, act=act, drop_p=drop_p, seed=seed)
+    return gemm(x, w, False, True, out=out, bias=bias, addend=addend, pre=pre, act=act, drop_p=drop_p, seed=seed,
+                ce_partials=ce_partials)
 
 
-def linear_dgrad(dy, w, out=None, addend=None, gelu_pre=None, drop_p=0.0, seed=0):
-    """dx = addend + dropout_mask * gelu'(gelu_pre) * (dy @ w); dy [M,N], w [N,K]."""
+def linear_dgrad(dy, w, out=None, addend=None, gelu_pre=None, drop_p=0.0, seed=0, ce=None):
+    """dx = addend + dropout_mask * gelu'(gelu_pre) * (dy @ w); dy [M,N], w [N,K].  ``ce``: see gemm (dy = logits)."""
     act = ACT_GELU_BWD if gelu_pre is not None else ACT_NONE
-    return gemm(dy, w, False, False, out=out, addend=addend, aux=gelu_pre, act=act, drop_p=drop_p, seed=seed)
+    return gemm(dy, w, False, False, out=out, addend=addend, aux=gelu_pre, act=act, drop_p=drop_p, seed=seed, ce=ce)
 
 
-def linear_wgrad(dy, x, dw=None, db=None):
-    """dw[N,K] = dy.T @ x, db[N] = column sums of dy (fused into the same kernel).
+def linear_wgrad(dy, x, dw=None, db=None, ce=None):
+    """dw[N,K] = dy.T @ x, db[N] = column sums of dy (fused into the same kernel).  ``ce``: see gemm (dy = logits).
 
     With a SideStream active and caller-owned outputs, the product is enqueued on the side stream
     (ordered after everything enqueued so far on the current stream) and the call returns at once."""
     if SIDE is not None and dw is not None:
-        SIDE.run(lambda: gemm(dy, x, True, False, out=dw, colsum=db), dy, x)
+        SIDE.run(lambda: gemm(dy, x, True, False, out=dw, colsum=db, ce=ce), dy, x)
         return dw
-    return gemm(dy, x, True, False, out=dw, colsum=db)
+    return gemm(dy, x, True, False, out=dw, colsum=db, ce=ce)
 
 
 def layernorm_fwd(x, gamma, beta, eps=1e-5, act=ACT_NONE, drop_p=0.0, seed=0, save_stats=True, out=None):
@@ -402,6 +503,35 @@ def softmax_ce(logits, targets, eps=0.1, grad_scale=None, want_grad=True, in_pla
                                   dl.stride(0) if dl is not None else 0, M, V, float(eps), float(gs), stream()),
           "capdec_softmax_ce")
     return loss_rows, dl
+
+
+def ce_tiles(M, V, K):
+    """Column tiles of the vocabulary product [M, K] x [V, K]^T in the current compute type (= second dimension of
+    its cross-entropy partials)."""
+    return lib().capdec_gemm_ce_tiles(M, V, K, COMPUTE_DTYPE)
+
+
+def ce_finalize(partials, logits, targets, eps=0.1):
+    """(lse [M], loss_rows [M]) from the per-tile softmax partials the vocabulary product left (fused cross-entropy)."""
+    _mat(logits, "ce_finalize.logits")
+    M, V = logits.shape
+    targets = _req(targets, "ce_finalize.targets", torch.int64).contiguous()
+    lse = torch.empty(M, dtype=torch.float32, device=logits.device)
+    rows = torch.empty(M, dtype=torch.float32, device=logits.device)
+    check(lib().capdec_ce_finalize(ptr(_req(partials, "ce_finalize.partials")), partials.shape[1], ptr(logits),
+                                   logits.stride(0), ptr(targets), ptr(lse), ptr(rows), M, V, float(eps), stream()),
+          "capdec_ce_finalize")
+    return lse, rows
+
+
+def ce_dlogits(logits, lse, targets, eps, grad_scale):
+    """logits -> dlogits in place (the pass form of the gradient transform the fp32 loaders do on the fly)."""
+    _mat(logits, "ce_dlogits.logits")
+    M, V = logits.shape
+    check(lib().capdec_ce_dlogits(ptr(logits), logits.stride(0), ptr(_req(lse, "ce_dlogits.lse")),
+                                  ptr(_req(targets, "ce_dlogits.targets", torch.int64).contiguous()), M, V, float(eps),
+                                  float(grad_scale), stream()), "capdec_ce_dlogits")
+    return logits
 
 
 def reduce_sum(x, scale=1.0):

@@ -86,7 +86,7 @@ class CaptionTrainer:
         dev = self.flat_p.device
         self.gnorm_sq = torch.zeros(1, dtype=torch.float32, device=dev)
         self.reducer = BucketReducer(self.flat_g, self.bucket_ranges, process_group, overlap)
-        self._logits = None
+        self._logits = self._ce_part = None
         self.side = ops.SideStream(dev) if (side_stream_wgrad and dev.type == "cuda") else None
         self._rows = None  # B*T of the first step; data-parallel ranks must all run this many rows (1/(rows*world))
         if self.world > 1:
@@ -165,13 +165,25 @@ class CaptionTrainer:
         if self._logits is None or tuple(self._logits.shape) != (B * T, self.P_head["3.weight"].shape[0]):
             self._logits = torch.empty((B * T, self.P_head["3.weight"].shape[0]), dtype=torch.float32,
                                        device=features.device)
-        logits = engine.head_fwd(self.P_head, y, dp, sv_head, logits_out=self._logits)
+        # label-smoothed CE fused into the vocabulary product: its epilogue leaves per-tile softmax partials, a tiny
+        # finalize gives lse / loss per row, and the two backward products read the LOGITS through the gradient
+        # transform in their loaders -- the [B*T, V] block is written once and never rewritten (fp32; the other
+        # compute types apply the same transform as one in-place pass)
+        V, K2 = self.P_head["3.weight"].shape
+        tiles = ops.ce_tiles(B * T, V, K2)
+        if self._ce_part is None or tuple(self._ce_part.shape) != (B * T, tiles, 4):
+            self._ce_part = torch.empty((B * T, tiles, 4), dtype=torch.float32, device=features.device)
+        logits = engine.head_fwd(self.P_head, y, dp, sv_head, logits_out=self._logits, ce_partials=self._ce_part)
         keep = logits.clone() if keep_logits else None
-        rows, dlogits = ops.softmax_ce(logits, tgt_out.view(-1), self.smooth, grad_scale=1.0 / (B * T * self.world),
-                                       in_place=True)
+        targets = tgt_out.view(-1)
+        lse, rows = ops.ce_finalize(self._ce_part, logits, targets, self.smooth)
         loss = ops.reduce_sum(rows, 1.0 / (B * T))
         nb = len(self.bucket_ranges)
-        dy = engine.head_bwd(self.P_head, self.G_head, sv_head, dlogits, dp)
+        ce = (lse, targets, self.smooth, 1.0 / (B * T * self.world))
+        if self.dtype != "fp32" or V % 4:  # the loader transform is exact-fp32, float4 loaders only
+            ops.ce_dlogits(logits, *ce)
+            ce = None
+        dy = engine.head_bwd(self.P_head, self.G_head, sv_head, logits, dp, ce=ce)
 
         lanes = tuple(self.side.streams) if self.side is not None else ()
 
@@ -189,6 +201,18 @@ class CaptionTrainer:
         self.reducer.reduce(0, after=lanes)
         self.reducer.finish()
         return loss, keep
+
+    def tune(self, features, captions, train=True, verbose=False):
+        """One-time set-up for a run of equally shaped steps: record the matrix products of one forward + backward
+        pass, time every candidate GEMM plan of each and pin the fastest in the library (``ops.tune_gemm_plans``).
+        Changes no parameter and no optimizer state; call it before the steps that matter are timed."""
+        ops.TUNE_RECORD = {}
+        try:
+            self.forward_backward(features, captions, train=train)
+        finally:
+            sigs, ops.TUNE_RECORD = ops.TUNE_RECORD, None
+        torch.cuda.synchronize()
+        return ops.tune_gemm_plans(sigs, verbose=verbose)
 
     def optimizer_step(self):
         self.step_count += 1

@@ -64,13 +64,42 @@ typedef struct capdec_epilogue {
     int act;
     float drop_p;
     uint64_t drop_seed;
+    /* label-smoothed cross-entropy fused into the vocabulary projection (ref train.py:41-50; all NULL = off):
+     *   forward  (logits = h W^T + b, transA = 0, bias only): ce_partials [M, capdec_gemm_ce_tiles(M,N,K,dtype)]
+     *            float4 receives, per row and column tile, (max, sum exp(z - max), sum z, -) of the logits the
+     *            same epilogue writes to C; capdec_ce_finalize turns them into lse / loss rows.
+     *   backward (the two products that consume dlogits: dW = dlogits^T h with transA = 1, dh = dlogits W with
+     *            transA = 0; transB = 0, dtype CAPDEC_F32): with ce_lse set, A holds the LOGITS and the A loaders
+     *            compute dlogits[r,v] = ce_grad_scale * (exp(z - ce_lse[r]) - ce_eps/V - (1 - ce_eps)*[v == ce_targets[r]])
+     *            on their way into LDS (colsum, the bias gradient, sees the transformed values): the [B*T, V]
+     *            block is written once by the forward product and only read afterwards. */
+    void* ce_partials;
+    const void* ce_lse;
+    const int64_t* ce_targets;
+    float ce_eps;
+    float ce_grad_scale;
 } capdec_epilogue;
 
+/* Split-K (chosen by the built-in cost model for small outputs with a long K, e.g. weight gradients) is combined
+ * INSIDE the launch: every K-slice writes its partial tile to the workspace, takes a ticket, and the last-arriving
+ * slice of a tile sums all slices in slice order (bitwise reproducible) and runs the epilogue -- no second
+ * launch.  Workspace contract: capdec_gemm_workspace_bytes() bytes, 16-byte aligned; its first
+ * CAPDEC_GEMM_TICKET_BYTES hold the tile tickets, which must be ZERO the first time a workspace is passed and are
+ * left zero by every call (so: zero a workspace once when allocating it, give capdec_gemm a workspace no other
+ * entry point writes to, and never share one workspace between GEMMs that may run concurrently on two streams). */
+#define CAPDEC_GEMM_TICKET_BYTES 16384
 size_t capdec_gemm_workspace_bytes(int M, int N, int K);
 /* Tuning hook (process-global, not thread-safe): force block tile bm x bn in {64,128}^2 and a split-K
  * factor (and k-tile bk in {0 = default, 16, 32}) for every following capdec_gemm call; bm = 0
  * restores the built-in cost model. */
 int capdec_gemm_tune(int bm, int bn, int split, int bk);
+/* Tuned plans: record the (tile, split, k-tile) a caller MEASURED to be fastest for one product -- transposes,
+ * shape and compute type -- on the device it runs on (the Python layer times the candidates once per shape,
+ * outside any timed region: ops.tune_gemm_plans).  A recorded plan replaces the cost model's choice in every
+ * later capdec_gemm / capdec_gemm_workspace_bytes / capdec_gemm_ce_tiles call of this process; bm = 0 erases one
+ * entry, capdec_gemm_plan_clear all.  A plan changes speed and the rounding order of the K sum, nothing else. */
+int capdec_gemm_plan_set(int transA, int transB, int M, int N, int K, int dtype, int bm, int bn, int split, int bk);
+void capdec_gemm_plan_clear(void);
 int capdec_gemm(int transA, int transB, int M, int N, int K, const void* A, int lda, const void* B, int ldb,
                 void* C, int ldc, const capdec_epilogue* ep, int dtype, void* workspace, size_t workspace_bytes,
                 capdec_stream_t stream);
@@ -158,6 +187,17 @@ int capdec_attn_bwd(const void* q, int ldq, const void* k, int ldk, const void* 
  */
 int capdec_softmax_ce(const void* logits, int ldl, const int64_t* targets, void* loss_rows, void* dlogits, int lddl,
                       int M, int V, float eps, float grad_scale, capdec_stream_t stream);
+/* The fused form of the same loss (capdec_epilogue.ce_*): the vocabulary product's epilogue leaves per-tile softmax
+ * partials, capdec_ce_finalize combines them per row -- lse[m] and loss_rows[m] as above (z_y is read from the
+ * logits) -- and the backward products read the logits through the gradient transform.  capdec_gemm_ce_tiles: the
+ * number of column tiles (second dimension of the partials) capdec_gemm will use for this shape and dtype.
+ * capdec_ce_dlogits: the same transform as a pass in place, for compute types whose loaders do not carry it
+ * (CAPDEC_BF16 / CAPDEC_F32X3) and for callers that want dlogits materialised. */
+int capdec_gemm_ce_tiles(int M, int N, int K, int dtype);
+int capdec_ce_finalize(const void* partials, int tiles, const void* logits, int ldl, const int64_t* targets, void* lse,
+                       void* loss_rows, int M, int V, float eps, capdec_stream_t stream);
+int capdec_ce_dlogits(void* logits, int ldl, const void* lse, const int64_t* targets, int M, int V, float eps,
+                      float grad_scale, capdec_stream_t stream);
 /* out[0] = scale * sum(x[0..n)) with a fixed (deterministic) reduction tree; workspace of
  * capdec_reduce_workspace_bytes() bytes. */
 size_t capdec_reduce_workspace_bytes(void);

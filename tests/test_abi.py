@@ -19,7 +19,7 @@ def test_header_binding_and_library_agree():
     lib = _capi.lib()  # raises if the .so is missing or lacks a declared symbol
     for name in declared:
         assert getattr(lib, name) is not None
-    assert lib.capdec_abi_version() == 1
+    assert lib.capdec_abi_version() == 2
 
 
 def test_argument_errors_are_reported_without_a_gpu():

@@ -111,6 +111,50 @@ def test_gemm_wgrad_colsum_splitk(M, N, K):
     assert torch.equal(dw, dw2) and torch.equal(db, db2)
 
 
+@pytest.mark.parametrize("dtype", ["fp32", "f32x3", "bf16"])
+def test_gemm_in_launch_splitk_combine_forced_plans(dtype):
+    """Split-K combined inside the launch (ticket + last-arriver sum in slice order): every forced (tile, split)
+    plan must give the unsplit result up to summation order, bit-identical run to run, for ragged shapes, with the
+    epilogue (bias / GELU / addend) applied exactly once and the bias-gradient column sum combined too."""
+    ops = _ops()
+    from imagecaption_amd import _capi
+    from imagecaption_amd._capi import ACT_GELU
+    l = _capi.lib()
+    g = torch.Generator().manual_seed(3)
+    tol = 2e-5 if dtype != "bf16" else 2e-2
+    try:
+        with ops.compute_dtype(dtype):
+            for (M, N, K) in ((200, 136, 1100), (512, 512, 5120), (70, 64, 2048)):
+                x, w = torch.randn(M, K, generator=g), torch.randn(N, K, generator=g) / 8
+                b, r = torch.randn(N, generator=g), torch.randn(M, N, generator=g)
+                dy = torch.randn(K, M, generator=g)
+                want = gelu(x.double() @ w.double().T + b.double()) + r.double()
+                xs, ws_, bs, rs, dys = x.to(DEV), w.to(DEV), b.to(DEV), r.to(DEV), dy.to(DEV)
+                a2 = torch.randn(K, N, generator=g).to(DEV)  # wgrad-shaped: out[M,N] = dy^T[M,K] @ a2[K,N]
+                want_tn = dys.double().cpu().T @ a2.double().cpu()
+                want_cs = dys.double().cpu().sum(0)
+                for bm, bn, split in ((64, 64, 4), (128, 64, 3), (128, 128, 2), (64, 128, 8), (64, 64, 16)):
+                    if dtype == "bf16" and (bm, bn) not in ((64, 64), (128, 128)):
+                        continue
+                    if dtype == "f32x3" and (bm, bn) == (64, 128):
+                        continue
+                    l.capdec_gemm_tune(bm, bn, split, 0)
+                    ops._WS_NEED.clear()
+                    outs = []
+                    for _ in range(2):
+                        o = ops.linear_fwd(xs, ws_, bs, act=ACT_GELU, addend=rs)
+                        cs = torch.empty(M, device=DEV)
+                        o2 = ops.gemm(dys, a2, True, False, colsum=cs)
+                        outs.append((o, o2, cs))
+                    assert relerr(outs[0][0], want) < tol, (M, N, K, bm, bn, split)
+                    assert relerr(outs[0][1], want_tn) < tol and relerr(outs[0][2], want_cs) < (2e-5 if dtype != "bf16" else 1e-2), (M, N, K, bm, bn, split)
+                    for a, c in zip(outs[0], outs[1]):
+                        assert torch.equal(a, c), (M, N, K, bm, bn, split)
+    finally:
+        l.capdec_gemm_tune(0, 0, 0, 0)
+        ops._WS_NEED.clear()
+
+
 def test_gemm_dropout_mask_statistics_and_reuse():
     ops = _ops()
     M, N, K = 512, 384, 32
@@ -293,6 +337,61 @@ def test_softmax_ce(M, V):
     # the in-place call's loss rows read z[y] while other waves overwrite the row: targets spread over every wave
     # of the block (ids >= 64 included) must give the bits of the out-of-place call
     assert torch.equal(rows2, rows)
+
+
+@pytest.mark.parametrize("dtype", ["fp32", "f32x3", "bf16"])
+@pytest.mark.parametrize("M,V,K", [(70, 200, 96), (260, 10000, 64), (40, 30001, 32)])
+def test_cross_entropy_fused_into_the_vocabulary_product(M, V, K, dtype):
+    """ref train.py:41-50 fused into the logits GEMM: epilogue partials + finalize == the dense one-hot / log_softmax
+    loss, and the two backward products reading LOGITS through the loader transform == the same products on
+    materialised dlogits.  Ragged M / V (last column tile partly outside), targets in every column tile."""
+    ops = _ops()
+    g = torch.Generator().manual_seed(M + V)
+    h = torch.randn(M, K, generator=g)
+    w = torch.randn(V, K, generator=g) * (3.0 / K ** 0.5)
+    b = torch.randn(V, generator=g)
+    y = torch.randint(0, V, (M,), generator=g)
+    y[:4] = torch.tensor([0, V - 1, V // 2, 63])
+    z = (h.double() @ w.double().T + b.double()).requires_grad_()
+    onehot = torch.zeros(M, V, dtype=torch.float64).scatter(1, y.unsqueeze(1), 1) * 0.9 + 0.1 / V
+    loss_ref = -(onehot * torch.log_softmax(z, -1)).sum(-1)
+    gs = 0.37 / M
+    (gz,) = torch.autograd.grad(loss_ref.sum() * gs, z)
+    tol = 1e-5 if dtype != "bf16" else 2e-2
+    with ops.compute_dtype(dtype):
+        hd, wd, bd, yd = h.to(DEV), w.to(DEV), b.to(DEV), y.to(DEV)
+        part = torch.full((M, ops.ce_tiles(M, V, K), 4), float("nan"), device=DEV)
+        logits = ops.linear_fwd(hd, wd, bd, ce_partials=part)
+        assert torch.equal(logits, ops.linear_fwd(hd, wd, bd))  # the partials do not disturb the product
+        lse, rows = ops.ce_finalize(part, logits, yd, 0.1)
+        rows_sep, dl_sep = ops.softmax_ce(logits, yd, 0.1, grad_scale=gs)  # the separate 3-pass kernel on the same logits
+        assert relerr(lse, torch.logsumexp(logits.double().cpu(), -1)) < 1e-6
+        assert relerr(rows, rows_sep) < 1e-5 and relerr(rows, loss_ref) < max(tol, 1e-5)
+        x2 = torch.randn(M, K, generator=g).to(DEV)      # wgrad partner  [rows, K]
+        w2 = torch.randn(V, K, generator=g).to(DEV) / 8  # dgrad partner  [V, K]
+        dw_ref, db_ref = torch.empty(V, K, device=DEV), torch.empty(V, device=DEV)
+        ops.gemm(dl_sep, x2, True, False, out=dw_ref, colsum=db_ref)
+        dh_ref = ops.gemm(dl_sep, w2, False, False)
+        ce = (lse, yd, 0.1, gs)
+        from imagecaption_amd._capi import CapdecError
+        if dtype == "fp32" and V % 4:
+            with pytest.raises(CapdecError, match="multiples of 4"):  # float4 loaders only: callers use the pass form
+                ops.gemm(logits, w2, False, False, ce=ce)
+        elif dtype == "fp32":
+            dw, db = torch.empty(V, K, device=DEV), torch.empty(V, device=DEV)
+            ops.gemm(logits, x2, True, False, out=dw, colsum=db, ce=ce)
+            dh = ops.gemm(logits, w2, False, False, ce=ce)
+            # same arithmetic as the materialised path up to the lse's last bits
+            assert relerr(dw, dw_ref) < 2e-5 and relerr(db, db_ref) < 2e-5 and relerr(dh, dh_ref) < 2e-5
+            assert relerr(dw, gz.T @ x2.double().cpu()) < 2e-5 and relerr(dh, gz @ w2.double().cpu()) < 2e-5
+            dw2 = torch.empty_like(dw)
+            ops.gemm(logits, x2, True, False, out=dw2, ce=ce)
+            assert torch.equal(dw, dw2)  # run-to-run identical
+        else:
+            with pytest.raises(CapdecError, match="CAPDEC_F32"):
+                ops.gemm(logits, w2, False, False, ce=ce)
+        dl = ops.ce_dlogits(logits.clone(), *ce)
+        assert relerr(dl, dl_sep) < 1e-5 and relerr(dl, gz) < max(tol, 1e-5)
 
 
 def test_sumsq_and_adamw_against_torch_optim():

@@ -9,8 +9,12 @@ SHAPES = [  # (ta, tb, M, N, K)
     (0, 1, 5120, 512, 512), (0, 0, 5120, 512, 512), (1, 0, 512, 512, 5120),
     (0, 1, 5120, 2048, 512), (0, 1, 5120, 512, 2048), (1, 0, 2048, 512, 5120), (1, 0, 512, 2048, 5120),
     (0, 1, 5120, 1536, 512), (1, 0, 1536, 512, 5120), (0, 1, 12544, 1024, 512), (1, 0, 1024, 512, 12544),
-    (0, 0, 12544, 512, 1024),
+    (0, 0, 12544, 512, 1024), (0, 1, 12544, 6144, 512), (0, 0, 12544, 512, 6144), (1, 0, 1024, 2048, 12544),
+    (0, 1, 5120, 1024, 512), (0, 0, 5120, 512, 1024), (1, 0, 1024, 512, 5120), (0, 0, 5120, 2048, 512),
+    (0, 0, 5120, 512, 2048), (0, 0, 5120, 512, 1536),
 ]
+if os.environ.get("SWEEP_ONLY"):
+    SHAPES = [s for i, s in enumerate(SHAPES) if str(i) in os.environ["SWEEP_ONLY"].split(",")]
 
 def timeit(fn, n=10):
     fn(); torch.cuda.synchronize()
@@ -35,7 +39,7 @@ for ta, tb, M, N, K in SHAPES:
     ops._WS_NEED.clear()
     t = timeit(lambda: ops.gemm(a, b, ta, tb, out=out))
     res.append(("auto", t))
-    for (bm, bn), sp, bk in itertools.product(CANDS, [1, 2, 4, 8, 16], BKS):
+    for (bm, bn), sp, bk in itertools.product(CANDS, [1, 2, 3, 4, 5, 6, 8, 10, 12, 16], BKS):
         if sp > 1 and K // sp < 128: continue
         if sp > 1 and M * N * sp * 4 > (1 << 30): continue
         l.capdec_gemm_tune(bm, bn, sp, bk)

@@ -216,6 +216,14 @@ def measured_hbm_copy_gbs():
     return best
 
 
+def profile_marker():
+    """A one-workgroup copy: marks the start of the measured part of the run in a rocprofv3 kernel trace
+    (tools/rocpd_stats.py --timed counts what follows it)."""
+    from imagecaption_amd._capi import check, lib, ptr, stream
+    buf = torch.zeros(64, dtype=torch.uint8, device="cuda")
+    check(lib().capdec_probe_copy(ptr(buf), ptr(buf[32:]), 16, stream()), "capdec_probe_copy")
+
+
 def timed_steps(trainer, feats, ids, steps, warmup, world, dev):
     """`warmup` untimed steps, then exactly `steps` steps between barrier + synchronize; MAX over ranks."""
     for _ in range(warmup):
@@ -372,6 +380,7 @@ def main():
     feats, ids = synth_batch(cfg, cfg["batch"], dev, rank)
     # one-time set-up, outside every timed region: measure the GEMM plans of this step's shapes on this device
     tuned = {} if args.no_tune else trainer.tune(feats, ids, verbose=args.detail)
+    profile_marker()
 
     dt, loss = timed_steps(trainer, feats, ids, args.steps, args.warmup, world, dev)
     loss_val = float(loss.item())

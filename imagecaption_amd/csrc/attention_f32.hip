@@ -179,6 +179,23 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(DH <= 64 ? 3
     const float* kg = p.k + (size_t)b * p.Tk * p.ldk + h * DH;
     const float* vg = p.v + (size_t)b * p.Tk * p.ldv + h * DH;
 
+    // Diagnostic builds only (tools/attn_stamps.py; never in the shipped library): -DCAPDEC_ATTN_STAMPS records
+    // s_memtime at the phase boundaries of every wave, -DCAPDEC_ATTN_NOMMA replaces the matrix products by a few
+    // vector operations (what the kernel costs with its arithmetic taken out).
+#ifdef CAPDEC_ATTN_STAMPS
+    unsigned long long st_[8];
+    int sti_ = 0;
+#define STAMP() do { if (sti_ < 8) st_[sti_++] = __builtin_amdgcn_s_memtime(); } while (0)
+#else
+#define STAMP() do { } while (0)
+#endif
+#ifdef CAPDEC_ATTN_TWICE
+    for (int rep_ = 0; rep_ < CAPDEC_ATTN_TWICE; ++rep_) {
+    asm volatile("" ::: "memory");
+#else
+    {
+#endif
+    STAMP();
     float4 qf[DH / 8], tr[DH / 8];
     const int query = q0 + l31;
     int kmax = p.Tk;
@@ -187,6 +204,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(DH <= 64 ? 3
     tile_gload<DH>(qf, qg, p.ldq, q0, p.Tq, lane);
     if (nkt > 0) tile_gload<DH>(tr, kg, p.ldk, 0, p.Tk, lane);
     tile_lstore<DH>(Ts, qf, p.scale, lane);
+    STAMP();  // 1: Q arrived
     __syncthreads();
     lds_frag<DH>(qf, Ts, l31, half);
     f32x16 oacc[DH / 32];
@@ -199,9 +217,19 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(DH <= 64 ? 3
         const int k0 = kt * 32;
         __syncthreads();
         tile_lstore<DH>(Ts, tr, 1.f, lane);  // K tile
+        if (kt == 0) STAMP();  // 2: K0 arrived and stored
         __syncthreads();
         tile_gload<DH>(tr, vg, p.ldv, k0, p.Tk, lane);  // V tile flies under the score MFMAs
+#ifdef CAPDEC_ATTN_NOMMA
+        f32x16 s;
+        for (int r = 0; r < 16; ++r) s[r] = Ts[l31 * LD + r] * qf[r % (DH / 8)].x;
+#else
         f32x16 s = mma_lds_reg<DH>(Ts, qf, l31, half);
+#endif
+#ifdef CAPDEC_ATTN_STAMPS
+        asm volatile("s_nop 0" : "+v"(s));
+        if (kt == 0) STAMP();  // 3: S done
+#endif
         float mloc = -INFINITY;
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
@@ -229,9 +257,11 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(DH <= 64 ? 3
 #pragma unroll
             for (int r = 0; r < 16; ++r) pr[r] = p.drop.apply(pr[r], base + (uint32_t)row_of(r, half));
         }
+        if (kt == 0) STAMP();  // 4: softmax + dropout done
         __syncthreads();  // every lane is done reading K
         if (lane < 32) line[lane] = alpha;
         tile_lstore<DH>(Ts, tr, 1.f, lane);  // V tile
+        if (kt == 0) STAMP();  // 5: V0 arrived and stored
         __syncthreads();
         if (kt + 1 < nkt) tile_gload<DH>(tr, kg, p.ldk, k0 + 32, p.Tk, lane);  // next K under the P V MFMAs
 #pragma unroll
@@ -243,8 +273,17 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(DH <= 64 ? 3
                 oacc[dt][4 * g + 2] *= t.z; oacc[dt][4 * g + 3] *= t.w;
             }
         }
+#ifdef CAPDEC_ATTN_NOMMA
+        for (int dt = 0; dt < DH / 32; ++dt) for (int r = 0; r < 16; ++r) oacc[dt][r] += pr[r] * Ts[r * LD + l31 + dt * 32];
+#else
         mma_acc_lds<DH>(oacc, pr, Ts, l31, half);
+#endif
+#ifdef CAPDEC_ATTN_STAMPS
+        asm volatile("s_nop 0" : "+v"(oacc[0]));
+        if (kt == 0) STAMP();  // 6: PV0 done
+#endif
     }
+    STAMP();  // loop done
     const float inv = l_run > 0.f ? 1.f / l_run : 0.f;
     float irow[16];
     spread_rows(line, inv, irow, lane, half);
@@ -259,6 +298,21 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(DH <= 64 ? 3
     }
     if (p.lse && lane < 32 && query < p.Tq)
         p.lse[(size_t)bh * p.Tq + query] = l_run > 0.f ? m_run + __logf(l_run) : INFINITY;
+    }
+#ifdef CAPDEC_ATTN_STAMPS
+    {
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        const unsigned long long end = __builtin_amdgcn_s_memtime();
+        // stamp area: after the [B*H*Tq] lse block, 10 x u64 per workgroup (8 stamps, end, HW_ID | XCC_ID << 32)
+        unsigned long long* dbg = reinterpret_cast<unsigned long long*>(p.lse + (((size_t)p.B * p.H * p.Tq + 1) & ~(size_t)1));
+        if (lane == 0) {
+            for (int i = 0; i < 8; ++i) dbg[(size_t)blockIdx.x * 10 + i] = i < sti_ ? st_[i] : 0ull;
+            dbg[(size_t)blockIdx.x * 10 + 8] = end;
+            dbg[(size_t)blockIdx.x * 10 + 9] = (unsigned long long)__builtin_amdgcn_s_getreg(0xf804 /* HW_REG_HW_ID */) |
+                                               ((unsigned long long)__builtin_amdgcn_s_getreg(0xf814 /* HW_REG_XCC_ID */) << 32);
+        }
+    }
+#endif
 }
 
 // dQ (and delta = rowsum(dO * O)); wave owns 32 queries.

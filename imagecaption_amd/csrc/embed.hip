@@ -89,24 +89,29 @@ __global__ __launch_bounds__(256) void embed_order_kernel(const int64_t* __restr
     if (m < BT) order[offset[clamp_id(ids[m], V)] + rank[m]] = m;
 }
 
-// one wave per 32-position chunk of the sorted list; part[j] (row j of [BT,d]) receives the sum of
-// the run of equal tokens that STARTS (within this chunk) at sorted position j.
-__global__ __launch_bounds__(256) void embed_partial_kernel(const int64_t* __restrict__ ids, const int* __restrict__ order,
-                                                             const float* __restrict__ dout, float* __restrict__ part,
-                                                             int BT, int d, int V, Dropout drop) {
-    const int lane = threadIdx.x & 63;
-    const int chunk = blockIdx.x * 4 + (threadIdx.x >> 6);
-    const int j0 = chunk * 32;
+// Chunk of the sorted list reduced by one wave.  Small chunks and one-wave workgroups: the launch has
+// (BT / CHUNK) x (d / 256) independent waves (640 at the bench shape) instead of a few dozen workgroups
+// walking their rows one after the other on a handful of CUs.
+constexpr int EMB_CHUNK = 16;
+
+// one wave per (EMB_CHUNK-position chunk of the sorted list, 256-column group); part[j] (row j of [BT,d]) receives
+// the sum of the run of equal tokens that STARTS (within this chunk) at sorted position j.
+__global__ __launch_bounds__(64) void embed_partial_kernel(const int64_t* __restrict__ ids, const int* __restrict__ order,
+                                                            const float* __restrict__ dout, float* __restrict__ part,
+                                                            int BT, int d, int V, Dropout drop) {
+    const int lane = threadIdx.x;
+    const int chunk = blockIdx.x;
+    const int j0 = chunk * EMB_CHUNK;
     if (j0 >= BT) return;
-    const int n = min(32, BT - j0);
+    const int n = min(EMB_CHUNK, BT - j0);
     int my_row = 0, my_id = -1;
     if (lane < n) {
         my_row = order[j0 + lane];
         my_id = clamp_id(ids[my_row], V);
     }
     const int nq = d >> 2;
-    for (int q0 = 0; q0 < nq; q0 += 64) {  // 256 columns per pass
-        const int q = q0 + lane;
+    {
+        const int q = blockIdx.y * 64 + lane;  // this wave's 256 columns
         const bool act = q < nq;
         float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
         int head = 0;
@@ -143,11 +148,13 @@ __global__ __launch_bounds__(256) void embed_partial_kernel(const int64_t* __res
     }
 }
 
-// one workgroup per token: dE[v] = part[a] + part[next multiple of 32 after a] + ... (< b), in order;
+// one workgroup per token: dE[v] = part[a] + part[next multiple of EMB_CHUNK after a] + ... (< b), in order;
 // the list is cut into 4 contiguous shares (one per wave), combined in wave order.
 __global__ __launch_bounds__(256) void embed_combine_kernel(const int* __restrict__ offset, const float* __restrict__ part,
                                                              float* __restrict__ dE, int d) {
-    __shared__ __attribute__((aligned(16))) float sh[4][2048];
+    // 4 x d floats, sized at launch: a fixed 32 KiB block kept this (tiny) kernel from sharing a CU with the
+    // weight-gradient products that run beside it on the other lane
+    extern __shared__ __attribute__((aligned(16))) float sh_dyn[];
     const int v = blockIdx.x;
     const int a = offset[v], b = offset[v + 1];
     float* dst = dE + (size_t)v * d;
@@ -157,23 +164,35 @@ __global__ __launch_bounds__(256) void embed_combine_kernel(const int* __restric
         for (int q = threadIdx.x; q < nq; q += 256) reinterpret_cast<float4*>(dst)[q] = make_float4(0.f, 0.f, 0.f, 0.f);
         return;
     }
-    const int first_b = (a / 32 + 1) * 32;                       // first chunk boundary after a
-    const int nh = 1 + (first_b < b ? (b - 1 - first_b) / 32 + 1 : 0);  // heads: a, first_b, first_b+32, ...
+    const int first_b = (a / EMB_CHUNK + 1) * EMB_CHUNK;                       // first chunk boundary after a
+    const int nh = 1 + (first_b < b ? (b - 1 - first_b) / EMB_CHUNK + 1 : 0);  // heads: a, first_b, first_b+CHUNK, ...
     const int share = (nh + 3) / 4;
     const int h0 = wave * share, h1 = min(nh, h0 + share);
     for (int q = lane; q < nq; q += 64) {
         float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
-        for (int h = h0; h < h1; ++h) {
-            const int pos = h == 0 ? a : first_b + (h - 1) * 32;
-            const float4 t = reinterpret_cast<const float4*>(part + (size_t)pos * d)[q];
-            acc.x += t.x; acc.y += t.y; acc.z += t.z; acc.w += t.w;
+        // eight partial rows are requested at a time and then added in head order (the order of the sum is the
+        // same as a one-by-one walk; a heavy token such as <PAD> has a hundred heads per wave)
+        for (int hb = h0; hb < h1; hb += 8) {
+            float4 t[8];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) {
+                const int h = hb + u;
+                const int pos = h == 0 ? a : first_b + (h - 1) * EMB_CHUNK;
+                t[u] = h < h1 ? reinterpret_cast<const float4*>(part + (size_t)pos * d)[q] : make_float4(0.f, 0.f, 0.f, 0.f);
+            }
+#pragma unroll
+            for (int u = 0; u < 8; ++u) {
+                if (hb + u < h1) {
+                    acc.x += t[u].x; acc.y += t[u].y; acc.z += t[u].z; acc.w += t[u].w;
+                }
+            }
         }
-        reinterpret_cast<float4*>(&sh[wave][0])[q] = acc;
+        reinterpret_cast<float4*>(&sh_dyn[wave * d])[q] = acc;
     }
     __syncthreads();
     for (int q = threadIdx.x; q < nq; q += 256) {
-        const float4 p0 = reinterpret_cast<const float4*>(&sh[0][0])[q], p1 = reinterpret_cast<const float4*>(&sh[1][0])[q];
-        const float4 p2 = reinterpret_cast<const float4*>(&sh[2][0])[q], p3 = reinterpret_cast<const float4*>(&sh[3][0])[q];
+        const float4 p0 = reinterpret_cast<const float4*>(&sh_dyn[0])[q], p1 = reinterpret_cast<const float4*>(&sh_dyn[d])[q];
+        const float4 p2 = reinterpret_cast<const float4*>(&sh_dyn[2 * d])[q], p3 = reinterpret_cast<const float4*>(&sh_dyn[3 * d])[q];
         reinterpret_cast<float4*>(dst)[q] = make_float4(((p0.x + p1.x) + p2.x) + p3.x, ((p0.y + p1.y) + p2.y) + p3.y,
                                                         ((p0.z + p1.z) + p2.z) + p3.z, ((p0.w + p1.w) + p2.w) + p3.w);
     }
@@ -250,9 +269,10 @@ extern "C" int capdec_embed_bwd_apply(const int64_t* ids, const void* dout, void
     const int* order = offset + V + 1 + BT;
     float* part = (float*)workspace + embed_ws_ints(BT, V);
     hipStream_t st = (hipStream_t)stream;
-    hipLaunchKernelGGL(embed_partial_kernel, dim3((BT + 127) / 128), dim3(256), 0, st, ids, order, (const float*)dout, part,
-                       BT, d, V, make_dropout(drop_p, drop_seed));
-    hipLaunchKernelGGL(embed_combine_kernel, dim3(V), dim3(256), 0, st, offset, (const float*)part, (float*)dE, d);
+    hipLaunchKernelGGL(embed_partial_kernel, dim3((BT + EMB_CHUNK - 1) / EMB_CHUNK, (d / 4 + 63) / 64), dim3(64), 0, st, ids,
+                       order, (const float*)dout, part, BT, d, V, make_dropout(drop_p, drop_seed));
+    hipLaunchKernelGGL(embed_combine_kernel, dim3(V), dim3(256), 4 * (size_t)d * sizeof(float), st, offset, (const float*)part,
+                       (float*)dE, d);
     return check_launch("capdec_embed_bwd_apply");
 }
 

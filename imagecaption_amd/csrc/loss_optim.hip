@@ -113,7 +113,14 @@ __global__ __launch_bounds__(256) void reduce_stage1_kernel(const float* __restr
     __shared__ float sh[4];
     float s = 0.f;
     const size_t stride = (size_t)gridDim.x * 256;
-    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n; i += stride) {
+    // 16 bytes per lane while whole float4s remain (x is 16-byte aligned: checked by the caller), then the tail;
+    // which elements a thread owns depends on n and the grid only, so the sum is reproducible
+    const size_t n4 = (reinterpret_cast<uintptr_t>(x) & 15u) == 0 ? n >> 2 : 0;
+    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n4; i += stride) {
+        const float4 v = reinterpret_cast<const float4*>(x)[i];
+        s += SQ ? (v.x * v.x + v.y * v.y) + (v.z * v.z + v.w * v.w) : (v.x + v.y) + (v.z + v.w);
+    }
+    for (size_t i = (n4 << 2) + (size_t)blockIdx.x * 256 + threadIdx.x; i < n; i += stride) {
         const float v = x[i];
         s += SQ ? v * v : v;
     }
@@ -206,7 +213,7 @@ static int reduce_impl(bool sq, const void* x, size_t n, float scale, void* out,
         set_error("%s: needs %zu workspace bytes, got %zu", what, RED_PARTS * sizeof(float), ws_bytes);
         return CAPDEC_ERR_WORKSPACE;
     }
-    size_t b = (n + 255) / 256;
+    size_t b = (n / 4 + 255) / 256;
     const int nb = (int)(b > RED_PARTS ? RED_PARTS : (b ? b : 1));
     hipStream_t st = (hipStream_t)stream;
     if (sq) hipLaunchKernelGGL((reduce_stage1_kernel<true>), dim3(nb), dim3(256), 0, st, (const float*)x, n, (float*)ws);

@@ -71,7 +71,7 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(const float* __restrict__ d
                                                       float* __restrict__ dx, float* __restrict__ dx_drop,
                                                       float* __restrict__ part, int M, int d, int act, Dropout drop,
                                                       Dropout drop2) {
-    __shared__ float red[4][2][NV * 256];
+    __shared__ float red[2][NV * 256];  // the four waves add their column partials into it one after the other
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int nq = d >> 2;
     const float4* g4 = reinterpret_cast<const float4*>(gamma);
@@ -138,18 +138,25 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(const float* __restrict__ d
             }
         }
     }
-    // block reduction of the per-wave partial column sums, then one partial row per block
+    // block reduction of the per-wave partial column sums in wave order (fixed: reproducible), in ONE [2][d] LDS
+    // image (4 KiB at d = 512; a per-wave image each cost 16 KiB and with it this kernel's place on CUs it shares
+    // with the weight-gradient products of the other lane), then one partial row per block
+    for (int w = 0; w < 4; ++w) {
+        if (wave == w) {
 #pragma unroll
-    for (int i = 0; i < NV; ++i)
+            for (int i = 0; i < NV; ++i)
 #pragma unroll
-        for (int j = 0; j < 4; ++j) {
-            red[wave][0][(lane + 64 * i) * 4 + j] = dg[i][j];
-            red[wave][1][(lane + 64 * i) * 4 + j] = db[i][j];
+                for (int j = 0; j < 4; ++j) {
+                    const int c = (lane + 64 * i) * 4 + j;
+                    red[0][c] = w == 0 ? dg[i][j] : red[0][c] + dg[i][j];
+                    red[1][c] = w == 0 ? db[i][j] : red[1][c] + db[i][j];
+                }
         }
-    __syncthreads();
+        __syncthreads();
+    }
     for (int c = threadIdx.x; c < d; c += 256) {
-        part[((size_t)blockIdx.x * 2 + 0) * d + c] = (red[0][0][c] + red[1][0][c]) + (red[2][0][c] + red[3][0][c]);
-        part[((size_t)blockIdx.x * 2 + 1) * d + c] = (red[0][1][c] + red[1][1][c]) + (red[2][1][c] + red[3][1][c]);
+        part[((size_t)blockIdx.x * 2 + 0) * d + c] = red[0][c];
+        part[((size_t)blockIdx.x * 2 + 1) * d + c] = red[1][c];
     }
 }
 
@@ -269,6 +276,42 @@ extern "C" int capdec_layernorm_bwd(const void* dy, const void* x, const void* g
     }
     return ln_bwd_launch("capdec_layernorm_bwd", dy, x, gamma, beta, mean, rstd, dx, dx_drop, dgamma, dbeta, M, d, act,
                          drop_p, drop_seed, drop2_p, drop2_seed, (float*)workspace, (hipStream_t)stream);
+}
+
+// The two halves of capdec_layernorm_bwd as separate calls: dx (+ dx_drop) and the per-workgroup column partials
+// first, the parameter gradients from those partials later -- e.g. on another stream: dgamma / dbeta are weight
+// gradients, nothing on the backward critical path waits for them.
+extern "C" int capdec_layernorm_bwd_dx(const void* dy, const void* x, const void* gamma, const void* beta, const void* mean,
+                                       const void* rstd, void* dx, void* dx_drop, void* partials, size_t partials_bytes,
+                                       int M, int d, int act, float drop_p, uint64_t drop_seed, float drop2_p,
+                                       uint64_t drop2_seed, capdec_stream_t stream) {
+    const char* what = "capdec_layernorm_bwd_dx";
+    float dummy;  // ln_bwd_check wants non-null parameter-gradient pointers; this call writes none
+    if (int rc = ln_bwd_check(what, dy, x, gamma, beta, mean, rstd, dx, dx_drop, &dummy, &dummy, M, d)) return rc;
+    const size_t need = (size_t)ln_blocks(M) * 2 * d * sizeof(float);
+    if (!partials || partials_bytes < need) {
+        set_error("%s: needs %zu bytes of partials, got %zu", what, need, partials_bytes);
+        return CAPDEC_ERR_WORKSPACE;
+    }
+    const Dropout dr = make_dropout(drop_p, drop_seed), dr2 = make_dropout(drop2_p, drop2_seed);
+    const int nv = (d + 255) / 256, nblk = ln_blocks(M);
+    hipStream_t st = (hipStream_t)stream;
+#define CALL(NV)                                                                                                     \
+    hipLaunchKernelGGL((ln_bwd_kernel<NV>), dim3(nblk), dim3(256), 0, st, (const float*)dy, (const float*)x,          \
+                       (const float*)gamma, (const float*)beta, (const float*)mean, (const float*)rstd, (float*)dx,   \
+                       (float*)dx_drop, (float*)partials, M, d, act, dr, dr2)
+    if (nv <= 1) { CALL(1); } else if (nv <= 2) { CALL(2); } else if (nv <= 4) { CALL(4); } else { CALL(8); }
+#undef CALL
+    return check_launch(what);
+}
+
+extern "C" int capdec_layernorm_bwd_dparams(const void* partials, void* dgamma, void* dbeta, int M, int d,
+                                            capdec_stream_t stream) {
+    CAPDEC_REQUIRE(partials && dgamma && dbeta && M > 0 && d > 0 && d % 4 == 0 && d <= 2048,
+                   "capdec_layernorm_bwd_dparams: bad arguments");
+    hipLaunchKernelGGL(ln_bwd_finalize_kernel, dim3((d + 15) / 16), dim3(256), 0, (hipStream_t)stream, (const float*)partials,
+                       (float*)dgamma, (float*)dbeta, ln_blocks(M), d);
+    return check_launch("capdec_layernorm_bwd_dparams");
 }
 
 // ---- the one entry point that allocates nothing (include/capdec.h: capdec_layernorm_bwd_noalloc) -------------

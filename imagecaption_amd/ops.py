@@ -368,6 +368,16 @@ def layernorm_bwd(dy, x, gamma, beta, mean, rstd, act=ACT_NONE, drop_p=0.0, seed
         dbeta = torch.empty(d, dtype=torch.float32, device=x.device)
     l = lib()
     need = l.capdec_layernorm_bwd_workspace_bytes(M, d)
+    if SIDE is not None:
+        # the parameter gradients are weight gradients: their reduction runs on the weight-gradient lane, from a
+        # private block of partials (the shared workspace would be overwritten by the next call on this stream)
+        part = torch.empty(need, dtype=torch.uint8, device=x.device)
+        check(l.capdec_layernorm_bwd_dx(ptr(dy), ptr(x), ptr(gamma), ptr(beta), ptr(mean), ptr(rstd), ptr(dx), ptr(dx_drop),
+                                        ptr(part), part.numel(), M, d, act, float(drop_p), int(seed), float(drop2_p),
+                                        int(seed2), stream()), "capdec_layernorm_bwd_dx")
+        SIDE.run(lambda: check(l.capdec_layernorm_bwd_dparams(ptr(part), ptr(dgamma), ptr(dbeta), M, d, stream()),
+                               "capdec_layernorm_bwd_dparams"), part, dgamma, dbeta)
+        return dx, dx_drop, dgamma, dbeta
     ws = _capi.workspace(need, x.device)
     check(l.capdec_layernorm_bwd(ptr(dy), ptr(x), ptr(gamma), ptr(beta), ptr(mean), ptr(rstd), ptr(dx), ptr(dx_drop),
                                  ptr(dgamma), ptr(dbeta), M, d, act, float(drop_p), int(seed), float(drop2_p),

@@ -86,7 +86,7 @@ class CaptionTrainer:
         dev = self.flat_p.device
         self.gnorm_sq = torch.zeros(1, dtype=torch.float32, device=dev)
         self.reducer = BucketReducer(self.flat_g, self.bucket_ranges, process_group, overlap)
-        self._logits = self._ce_part = None
+        self._logits = self._ce_part = self._embed_ws = None
         self.side = ops.SideStream(dev) if (side_stream_wgrad and dev.type == "cuda") else None
         self._rows = None  # B*T of the first step; data-parallel ranks must all run this many rows (1/(rows*world))
         if self.world > 1:
@@ -155,6 +155,19 @@ class CaptionTrainer:
         f2 = features.reshape(-1, features.shape[-1])
         S = 1 if features.dim() == 2 else features.shape[1]
         sv_proj, sv_stack, sv_head = {}, {}, {}
+        # the embedding gradient's row sort depends on the token ids only: it runs now, on the (idle) weight-gradient
+        # lane beside the forward pass, so that only the summation is left on the critical path at the end of backward
+        V_emb, d_emb = m.embedding.weight.shape
+        if self._embed_ws is None or self._embed_ws[0] != (B, T):
+            self._embed_ws = ((B, T), ops.embed_bwd_workspace(B, T, d_emb, V_emb, features.device))
+        embed_ws = self._embed_ws[1]
+        plan_done = None
+        if self.side is not None:
+            self.side.run(lambda: ops.embed_bwd_plan(tgt_in, d_emb, V_emb, embed_ws), tgt_in)
+            plan_done = torch.cuda.Event()
+            plan_done.record(self.side.stream)
+        else:
+            ops.embed_bwd_plan(tgt_in, d_emb, V_emb, embed_ws)
         mem = engine.proj_fwd(self.P_proj, f2, dp, sv_proj)
         x = ops.embed_fwd(tgt_in, m.embedding.weight, m.pos_encoder.table(), 0, dp.p, dp.seed(engine.S_EMBED))
         dec = m.transformer_decoder
@@ -196,8 +209,10 @@ class CaptionTrainer:
         dx, dmem = engine.stack_bwd(self.P_layers, self.G_layers, dec.norm.weight, dec.norm.bias, dec.norm.weight.grad,
                                     dec.norm.bias.grad, sv_stack, dy, mem, B, T, S, self.nhead, True, dp, after_layer)
         engine.proj_bwd(self.P_proj, self.G_proj, sv_proj, dmem, dp)
-        ops.embed_bwd(tgt_in, dx.view(B, T, -1), m.embedding.weight.shape[0], dp.p, dp.seed(engine.S_EMBED),
-                      dE=m.embedding.weight.grad)
+        if plan_done is not None:
+            torch.cuda.current_stream().wait_event(plan_done)
+        ops.embed_bwd(tgt_in, dx.view(B, T, -1), V_emb, dp.p, dp.seed(engine.S_EMBED), dE=m.embedding.weight.grad,
+                      planned_ws=embed_ws)
         self.reducer.reduce(0, after=lanes)
         self.reducer.finish()
         return loss, keep

@@ -121,6 +121,15 @@ int capdec_layernorm_bwd(const void* dy, const void* x, const void* gamma, const
                          int act, float drop_p, uint64_t drop_seed, float drop2_p, uint64_t drop2_seed,
                          void* workspace, size_t workspace_bytes, capdec_stream_t stream);
 
+/* The two halves of capdec_layernorm_bwd as separate calls: _dx writes dx (+ dx_drop) and the column partials
+ * (capdec_layernorm_bwd_workspace_bytes(M, d) bytes, caller-owned), _dparams turns those partials into dgamma /
+ * dbeta later -- on another stream if the caller likes: they are weight gradients, off the backward critical path. */
+int capdec_layernorm_bwd_dx(const void* dy, const void* x, const void* gamma, const void* beta, const void* mean,
+                            const void* rstd, void* dx, void* dx_drop, void* partials, size_t partials_bytes, int M,
+                            int d, int act, float drop_p, uint64_t drop_seed, float drop2_p, uint64_t drop2_seed,
+                            capdec_stream_t stream);
+int capdec_layernorm_bwd_dparams(const void* partials, void* dgamma, void* dbeta, int M, int d, capdec_stream_t stream);
+
 /* capdec_layernorm_bwd_noalloc: capdec_layernorm_bwd for callers that CANNOT allocate or bring a workspace --
  * code under HIP graph capture, tight serving / fine-tuning loops, harnesses that forbid hipMalloc.  It has NO
  * counterpart in the reference (which never manages memory itself); same arguments minus the workspace, same

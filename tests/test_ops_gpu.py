@@ -248,7 +248,11 @@ def _attn_ref(q, k, v, H, causal):
 @pytest.mark.parametrize("B,H,Tq,Tk,dh,causal", [
     (2, 2, 12, 12, 32, True), (2, 2, 12, 5, 32, False), (3, 8, 20, 20, 64, True), (3, 8, 20, 49, 64, False),
     (2, 8, 20, 1, 64, False), (1, 4, 299, 299, 64, True), (2, 2, 70, 33, 64, False), (1, 8, 20, 196, 128, False),
-    (2, 3, 40, 40, 128, True), (2, 2, 1, 37, 64, True), (1, 1, 33, 65, 32, False)])
+    (2, 3, 40, 40, 128, True), (2, 2, 1, 37, 64, True), (1, 1, 33, 65, 32, False),
+    # one query tile, key tiles across the waves of a workgroup (split forward, fused backward): 8 waves, ragged last
+    # tile, causal with more keys than queries, dh = 128 (forward split, backward two kernels)
+    (2, 8, 32, 256, 64, False), (3, 2, 32, 225, 32, False), (2, 4, 20, 96, 64, True), (2, 4, 31, 96, 128, False),
+    (9, 8, 5, 64, 64, False)])
 def test_attention_fwd_bwd(B, H, Tq, Tk, dh, causal):
     ops = _ops()
     D = H * dh
@@ -291,7 +295,12 @@ def test_attention_dropout_consistent_fwd_bwd():
     can be read out of the forward by feeding identity-like V blocks.
     """
     ops = _ops()
-    B, H, Tq, Tk, dh = 1, 1, 20, 32, 32
+    _dropout_consistency(ops, 1, 1, 20, 32, 32)
+    _dropout_consistency(ops, 1, 1, 20, 64, 64)   # two waves per (b, h): the mask indices must not depend on the split
+    _dropout_consistency(ops, 1, 1, 40, 64, 64)   # two query tiles: the flash-loop kernels
+
+
+def _dropout_consistency(ops, B, H, Tq, Tk, dh):
     g = torch.Generator().manual_seed(21)
     q, k = torch.randn(B * Tq, dh, generator=g), torch.randn(B * Tk, dh, generator=g)
     eye = torch.eye(Tk, dh)  # Tk == dh: o = A

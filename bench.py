@@ -53,6 +53,28 @@ def synth_batch(cfg, batch, device, rank):
     return feats.to(device), ids.to(device)
 
 
+def c1_batch(cfg, batch, device, rank, split="train"):
+    """BASELINE.json configs[0] (C1): the reference's own captions -- the committed uint8 token fixture made from
+    data/train_captions.json by oracle/gen_golden.py, every row padded to max_len 300 with <PAD> (ref main.py:36,
+    dataset.py:213-228) -- and seeded synthetic [B, 768] features in the image slot (the ViT is out of scope)."""
+    import numpy as np
+    z = np.load(os.path.join(ROOT, "tests", "golden", f"captions_{split}.npz"))
+    lens = z["lengths"].astype(np.int64)
+    starts = np.concatenate([[0], np.cumsum(lens)[:-1]])
+    T1 = cfg["T"] + 1
+    ids = torch.zeros((batch, T1), dtype=torch.int64)
+    for i in range(batch):
+        j = (rank * batch + i) % len(lens)
+        n = min(int(lens[j]), T1)
+        ids[i, :n] = torch.from_numpy(z["tokens"][starts[j]:starts[j] + n].astype(np.int64))
+    g = torch.Generator().manual_seed(42 + rank)
+    return torch.randn((batch, cfg["din"]), generator=g).to(device), ids.to(device)
+
+
+def make_batch(name, cfg, batch, device, rank):
+    return c1_batch(cfg, batch, device, rank) if name == "c1" else synth_batch(cfg, batch, device, rank)
+
+
 def train_flops_per_image(cfg):
     """forward FLOPs (2*MAC) per image; training = 3x."""
     L, T, S, d, V, din = cfg["layers"], cfg["T"], cfg["S"], cfg["d"], cfg["vocab"], cfg["din"]
@@ -73,23 +95,59 @@ def decode_flops_per_image(cfg, W, T):
     return once + W * T * per_tok
 
 
-def cpu_baseline(cfg, steps=2):
-    """The reference's CPU path (stock torch.nn decoder, oracle/torch_oracle.py) on this box's host cores."""
+def cpu_train(name, cfg, steps, warmup, threads):
+    """`steps` timed training steps of the oracle (stock torch.nn, the reference's CPU path) on the host cores."""
     from oracle.torch_oracle import OracleCaptionDecoder, train_step
-    threads = min(16, os.cpu_count() or 1)
-    torch.set_num_threads(threads)
     torch.manual_seed(42)
     model = OracleCaptionDecoder(cfg["vocab"], cfg["d"], cfg["heads"], cfg["layers"], cfg["din"]).train()
     opt = torch.optim.AdamW(model.parameters(), lr=1e-3, weight_decay=0.01)
-    feats, ids = synth_batch(cfg, cfg["batch"], "cpu", 0)
-    train_step(model, opt, feats, ids)  # warm-up
+    feats, ids = make_batch(name, cfg, cfg["batch"], "cpu", 0)
+    for _ in range(warmup):
+        train_step(model, opt, feats, ids)
     t0 = time.perf_counter()
     for _ in range(steps):
         train_step(model, opt, feats, ids)
     dt = (time.perf_counter() - t0) / steps
-    return {"value": cfg["batch"] / dt, "unit": "images/s", "cores": threads, "kind": "port",
-            "sample": f"{steps} timed training steps (after 1 warm-up) of the same workload, batch {cfg['batch']}, "
-                      f"stock torch.nn fp32 on {threads} host threads, {dt:.2f} s/step"}
+    return model, feats, {"value": cfg["batch"] / dt, "unit": "images/s", "cores": threads, "kind": "port",
+                          "sample": f"{steps} timed training steps (after {warmup} warm-up) of the same workload, batch "
+                                    f"{cfg['batch']}, stock torch.nn fp32 on {threads} host threads, {dt:.2f} s/step"}
+
+
+def cpu_baseline(name, cfg, extra=True, full=False):
+    """The reference's CPU path (oracle/torch_oracle.py) on this box's host cores, BASELINE.md's plan on bounded
+    samples: the bench workload itself (3 steps) is the `cpu_baseline` object; `also` holds C1 -- 10 training steps at
+    batch 32 on the reference's own captions, then greedy decode of a test slice -- and, with --cpu-full, 3 C3 steps
+    and the CPU beam-5 restatement on 256 images (minutes of CPU time: not part of the default run)."""
+    from oracle.torch_oracle import beam_decode, greedy_decode
+    threads = min(16, os.cpu_count() or 1)
+    torch.set_num_threads(threads)
+    model, feats, out = cpu_train(name, cfg, 3, 1, threads)
+    also = {}
+    if full:
+        n = 256
+        f = feats[:n] if feats.shape[0] >= n else feats
+        t0 = time.perf_counter()
+        beam_decode(model, f, beam=5, max_len=20)
+        dt = time.perf_counter() - t0
+        also["beam5_captions_per_sec"] = {"value": f.shape[0] / dt, "unit": "captions/s", "cores": threads,
+                                          "sample": f"CPU beam-5 restatement, length 20, {f.shape[0]} images of the bench "
+                                                    f"workload's shape, {dt:.1f} s"}
+        c3 = dict(CONFIGS["c3"])
+        also["c3_train"] = cpu_train("c3", c3, 3, 0, threads)[2]
+    if extra and name != "c1":
+        c1 = dict(CONFIGS["c1"])
+        m1, f1, r1 = cpu_train("c1", c1, 10, 2, threads)
+        also["c1_train"] = r1
+        n = 8
+        t0 = time.perf_counter()
+        greedy_decode(m1, f1[:n], max_len=20)
+        dt = time.perf_counter() - t0
+        also["c1_greedy_captions_per_sec"] = {"value": n / dt, "unit": "captions/s", "cores": threads,
+                                              "sample": f"oracle greedy decode (full-prefix recompute, as the reference's "
+                                                        f"loop does), {n} images, length 20, {dt:.2f} s"}
+    if also:
+        out["also"] = also
+    return out
 
 
 def decode_bench(model, cfg, dev, rank, world, dtype="fp32", images=4096, max_len=20):
@@ -153,7 +211,9 @@ def measured_mfma_peak(dtype):
 
 def vocab_traffic(config):
     """HBM-side bytes per launch of the vocab GEMM from the committed PMC passes (profiles/), C2 only."""
-    path = os.path.join(ROOT, "profiles", "r01_vocab_gemm_traffic.json")
+    path = os.path.join(ROOT, "profiles", "r02_vocab_gemm_traffic.json")
+    if not os.path.exists(path):
+        path = os.path.join(ROOT, "profiles", "r01_vocab_gemm_traffic.json")
     if config != "c2" or not os.path.exists(path):
         return None
     with open(path) as f:
@@ -245,6 +305,77 @@ def timed_steps(trainer, feats, ids, steps, warmup, world, dev):
     return dt, loss
 
 
+def roofline_block(cfg, dtype, agg, detail, traffic=None, with_peaks=True):
+    """`roofline` (the dominant launch: vocabulary-projection forward), `gemm_all` and `attention` from the
+    per-launch HIP-event records of profile_step."""
+    gemm_flops = sum(a[1] for k, a in agg.items() if k.startswith("gemm"))
+    gemm_time = sum(a[3] for k, a in agg.items() if k.startswith("gemm"))
+    gemm_n = sum(a[0] for k, a in agg.items() if k.startswith("gemm"))
+    ach = gemm_flops / gemm_time / 1e12 if gemm_time > 0 else 0.0
+    attn = {k: a for k, a in agg.items() if k.startswith("attn")}
+    attn_b = sum(a[2] for a in attn.values())
+    attn_t = sum(a[3] for a in attn.values())
+    peak = mfma_peak(dtype)
+    vk = f"gemm_nt_{cfg['batch'] * cfg['T']}x{cfg['vocab']}x{2 * cfg['d']}"
+    vocab = detail.get(vk)
+    kname = {"fp32": "f32", "f32x3": "f32x3", "bf16": "bf16"}[dtype]
+    roof = None
+    if vocab:
+        roof = {"bound": "mfma", "achieved": vocab[1] / vocab[3] / 1e12, "peak": peak, "unit": "TFLOP/s",
+                "frac": vocab[1] / vocab[3] / 1e12 / peak, "traffic": traffic,
+                "kernel": f"gemm_{kname}_kernel, vocab projection forward {vk[8:]} with the cross-entropy partials in its "
+                          f"epilogue (one launch per step)",
+                "ms": vocab[3] * 1e3 / vocab[0]}
+        if with_peaks:
+            roof["peak_measured"] = measured_mfma_peak("fp32" if dtype == "fp32" else "bf16") / (6.0 if dtype == "f32x3" else 1.0)
+    att = {"bound": "hbm", "achieved": attn_b / attn_t / 1e9 if attn_t else 0.0, "peak": PEAK_HBM_GBS, "unit": "GB/s",
+           "frac": (attn_b / attn_t / 1e9 / PEAK_HBM_GBS) if attn_t else 0.0, "ms_per_step": attn_t * 1e3,
+           "launches_per_step": sum(a[0] for a in attn.values())}
+    if with_peaks:
+        att["peak_measured"] = measured_hbm_copy_gbs()
+    return {"roofline": roof,
+            "gemm_all": {"bound": "mfma", "achieved": ach, "peak": peak, "unit": "TFLOP/s", "frac": ach / peak,
+                         "launches_per_step": gemm_n, "ms_per_step": gemm_time * 1e3},
+            "attention": att}
+
+
+def run_leg(name, dtype, steps, warmup, dev, rank, world, args):
+    """Another BASELINE configuration timed by the same harness (its own model, trainer, measured GEMM plans and
+    roofline); never the headline `value`."""
+    from imagecaption_amd import ImageCaptioningModel
+    from imagecaption_amd.trainer import CaptionTrainer
+    cfg = dict(CONFIGS[name])
+    torch.manual_seed(42)
+    model = ImageCaptioningModel(cfg["vocab"], cfg["d"], cfg["heads"], cfg["layers"], feature_dim=cfg["din"]).to(dev)
+    model.train()
+    tr = CaptionTrainer(model, dropout=0.0 if args.no_dropout else 0.1, seed=42, dtype=dtype,
+                        side_stream_wgrad=not args.no_side_streams)
+    feats, ids = make_batch(name, cfg, cfg["batch"], dev, rank)
+    if not args.no_tune:
+        tr.tune(feats, ids)
+    dt, loss = timed_steps(tr, feats, ids, steps, warmup, world, dev)
+    agg, detail = profile_step(tr, feats, ids, reps=2)
+    value = cfg["batch"] * world * steps / dt
+    out = {"metric": "train_images_per_sec", "value": value, "unit": "images/s", "ms_per_step": dt / steps * 1e3,
+           "steps": steps, "warmup": warmup, "dtype": {"fp32": "f32", "f32x3": "f32x3", "bf16": "bf16 products, fp32 storage"}[dtype],
+           "loss": float(loss.item()), "params": tr.n_params,
+           "config": {"workload": LEG_WORKLOADS[name], "global_batch": cfg["batch"] * world, "seq_len": cfg["T"],
+                      "memory_len": cfg["S"]},
+           "step_tflops_algorithmic": train_flops_per_image(cfg) * value / 1e12}
+    out.update(roofline_block(cfg, dtype, agg, detail, with_peaks=False))
+    del tr, model
+    torch.cuda.empty_cache()
+    return out
+
+
+LEG_WORKLOADS = {
+    "c1": "BASELINE.json configs[0] (C1): the repo's own model shape (d 512, 6 layers, vocab 108, max_len 300, memory of ONE "
+          "projected 768-d vector), batch 32, the reference's training captions (committed token fixture), synthetic features",
+    "c3": "BASELINE.json configs[2] (C3): 14x14x512 grid features (196 memory positions), hidden 1024, vocab 30000, len 20, "
+          "batch 256, bf16 matrix products",
+}
+
+
 def _free_port():
     import socket
     s = socket.socket()
@@ -323,6 +454,8 @@ def main():
                     help="images per GPU for the decode leg (BASELINE configs[4]: 100k images over 8 GPUs)")
     ap.add_argument("--detail", action="store_true", help="print the per-shape kernel table to stderr")
     ap.add_argument("--no-modes", action="store_true", help="skip the f32x3 / bf16 legs of the default fp32 run")
+    ap.add_argument("--no-legs", action="store_true", help="skip the C1 (fp32) and C3 (bf16) legs of the default run")
+    ap.add_argument("--cpu-full", action="store_true", help="CPU baseline also for C3 (3 steps) and beam-5 (256 images): minutes")
     ap.add_argument("--no-tune", action="store_true", help="keep the cost model's GEMM plans (skip the measured-plan set-up)")
     ap.add_argument("--launch-check", action="store_true",
                     help="only start the ranks, all-reduce once and report the group size (no kernels; works on CPU)")
@@ -377,7 +510,7 @@ def main():
     model.train()
     trainer = CaptionTrainer(model, dropout=0.0 if args.no_dropout else 0.1, seed=42, dtype=args.dtype,
                              side_stream_wgrad=not args.no_side_streams)
-    feats, ids = synth_batch(cfg, cfg["batch"], dev, rank)
+    feats, ids = make_batch(args.config, cfg, cfg["batch"], dev, rank)
     # one-time set-up, outside every timed region: measure the GEMM plans of this step's shapes on this device
     tuned = {} if args.no_tune else trainer.tune(feats, ids, verbose=args.detail)
     profile_marker()
@@ -406,20 +539,15 @@ def main():
                            "arithmetic": "fp32 operands split into 3 bf16 terms, six bf16 MFMA products, fp32-level accuracy"
                            if mode == "f32x3" else "bf16 MFMA products, fp32 accumulate / storage / optimizer"}
             del t2, m2
+    # the other BASELINE configurations, timed by the same harness in the same run (N = 1 only, like cpu_baseline)
+    legs = {}
+    if args.config == "c2" and args.dtype == "fp32" and not args.no_legs and world == 1:
+        legs["c1_fp32"] = run_leg("c1", "fp32", max(5, args.steps // 2), 3, dev, rank, world, args)
+        legs["c3_bf16"] = run_leg("c3", "bf16", max(5, args.steps // 2), 3, dev, rank, world, args)
     out = None
     if rank == 0:
         ms = dt / args.steps * 1e3
         value = cfg["batch"] * world * args.steps / dt
-        gemm_flops = sum(a[1] for k, a in agg.items() if k.startswith("gemm"))
-        gemm_time = sum(a[3] for k, a in agg.items() if k.startswith("gemm"))
-        gemm_n = sum(a[0] for k, a in agg.items() if k.startswith("gemm"))
-        ach = gemm_flops / gemm_time / 1e12 if gemm_time > 0 else 0.0
-        attn = {k: a for k, a in agg.items() if k.startswith("attn")}
-        attn_b = sum(a[2] for a in attn.values())
-        attn_t = sum(a[3] for a in attn.values())
-        peak = mfma_peak(args.dtype)
-        vk = f"gemm_nt_{cfg['batch'] * cfg['T']}x{cfg['vocab']}x{2 * cfg['d']}"
-        vocab = detail.get(vk)
         out = {
             "metric": "train_images_per_sec", "value": value, "unit": "images/s", "n_gpus": world,
             # size of the process group the gradient all-reduce really ran on (RCCL when backend == "nccl")
@@ -430,34 +558,24 @@ def main():
             "config": {"workload": f"BASELINE.json configs[1] (C2): 7x7x2048 grid features, hidden {cfg['d']}, "
                                    f"{cfg['layers']} layers, vocab {cfg['vocab']}, len {cfg['T']}, batch "
                                    f"{cfg['batch']}/GPU, teacher-forced train step incl. dropout, clip, AdamW"
-                       if args.config == "c2" else args.config,
+                       if args.config == "c2" else LEG_WORKLOADS.get(args.config, args.config),
                        "global_batch": cfg["batch"] * world, "seq_len": cfg["T"], "memory_len": cfg["S"],
                        "parallelism": f"dp{world}", "params": trainer.n_params},
             "loss": loss_val,
             "gemm_plans_tuned": sum(1 for v in tuned.values() if v[0] is not None),
             "modes": modes,
+            "legs": legs,
             "decode": decode,
             "step_tflops_algorithmic": train_flops_per_image(cfg) * value / 1e12,
-            "roofline": ({"bound": "mfma", "achieved": vocab[1] / vocab[3] / 1e12, "peak": peak,
-                          "unit": "TFLOP/s", "frac": vocab[1] / vocab[3] / 1e12 / peak,
-                          "traffic": vocab_traffic(args.config) if args.dtype == "fp32" else None,
-                          "kernel": f"gemm_{ {'fp32': 'f32', 'f32x3': 'f32x3', 'bf16': 'bf16'}[args.dtype] }_kernel, vocab projection forward {vk[8:]} (one launch per step)",
-                          "ms": vocab[3] * 1e3 / vocab[0],
-                          "peak_measured": measured_mfma_peak("fp32" if args.dtype == "fp32" else "bf16") / (6.0 if args.dtype == "f32x3" else 1.0)} if vocab else None),
-            "gemm_all": {"bound": "mfma", "achieved": ach, "peak": peak, "unit": "TFLOP/s",
-                         "frac": ach / peak, "launches_per_step": gemm_n,
-                         "ms_per_step": gemm_time * 1e3},
-            "attention": {"bound": "hbm", "achieved": attn_b / attn_t / 1e9 if attn_t else 0.0, "peak": PEAK_HBM_GBS,
-                          "unit": "GB/s", "frac": (attn_b / attn_t / 1e9 / PEAK_HBM_GBS) if attn_t else 0.0,
-                          "ms_per_step": attn_t * 1e3, "launches_per_step": sum(a[0] for a in attn.values()),
-                          "peak_measured": measured_hbm_copy_gbs()},
         }
+        out.update(roofline_block(cfg, args.dtype, agg, detail,
+                                  traffic=vocab_traffic(args.config) if args.dtype == "fp32" else None))
         if args.detail:
             for k, d in sorted(detail.items(), key=lambda kv: -kv[1][3]):
                 print(f"{k:42s} n={d[0]:3d} {d[3] * 1e3:8.3f} ms  {d[1] / d[3] / 1e12:7.2f} TF/s"
                       + (f"  {d[2] / d[3] / 1e9:8.1f} GB/s" if d[2] else ""), file=sys.stderr)
         if world == 1 and not args.no_cpu_baseline:
-            out["cpu_baseline"] = cpu_baseline(cfg)
+            out["cpu_baseline"] = cpu_baseline(args.config, cfg, extra=not args.no_legs, full=args.cpu_full)
         sys.stdout.flush()
         os.dup2(saved_stdout, 1)
         print(json.dumps(out), flush=True)

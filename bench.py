@@ -562,7 +562,8 @@ def main():
                        "global_batch": cfg["batch"] * world, "seq_len": cfg["T"], "memory_len": cfg["S"],
                        "parallelism": f"dp{world}", "params": trainer.n_params},
             "loss": loss_val,
-            "gemm_plans_tuned": sum(1 for v in tuned.values() if v[0] is not None),
+            "gemm_plans_tuned": sum(1 for k, v in tuned.items() if k != "ce_backward" and v[0] is not None),
+            "ce_backward": trainer.ce_backward,
             "modes": modes,
             "legs": legs,
             "decode": decode,

@@ -59,11 +59,15 @@ class FusedAdamW(torch.optim.Optimizer):
 class CaptionTrainer:
     def __init__(self, model, lr=1e-3, betas=(0.9, 0.999), eps=1e-8, weight_decay=0.01, max_norm=1.0,
                  smooth_factor=0.1, dropout=0.1, seed=0, process_group=None, overlap=True, dtype="fp32",
-                 side_stream_wgrad=True):
+                 side_stream_wgrad=True, ce_backward="loader"):
         self.model = model
         self.optimizer = FusedAdamW(self, list(model.parameters()), lr, betas, eps, weight_decay)
         self.max_norm, self.smooth, self.p, self.seed = max_norm, smooth_factor, dropout, seed
         self.pg = process_group
+        # how the two backward products of the vocabulary projection get dlogits: "loader" = they read the LOGITS
+        # through the gradient transform in their operand loaders (nothing is written back); "pass" = one in-place
+        # streaming pass turns the block into dlogits first.  tune() measures both and keeps the faster.
+        self.ce_backward = ce_backward
         # "fp32" (exact fp32 MFMA, the reference's precision), "f32x3" (split-bf16 products, fp32-level accuracy)
         # or "bf16" (bf16 MFMA products, fp32 everything else)
         self.dtype = dtype
@@ -193,7 +197,7 @@ class CaptionTrainer:
         loss = ops.reduce_sum(rows, 1.0 / (B * T))
         nb = len(self.bucket_ranges)
         ce = (lse, targets, self.smooth, 1.0 / (B * T * self.world))
-        if self.dtype != "fp32" or V % 4:  # the loader transform is exact-fp32, float4 loaders only
+        if self.dtype != "fp32" or V % 4 or self.ce_backward == "pass":  # the loader transform: exact fp32, float4 loaders
             ops.ce_dlogits(logits, *ce)
             ce = None
         dy = engine.head_bwd(self.P_head, self.G_head, sv_head, logits, dp, ce=ce)
@@ -222,12 +226,36 @@ class CaptionTrainer:
         pass, time every candidate GEMM plan of each and pin the fastest in the library (``ops.tune_gemm_plans``).
         Changes no parameter and no optimizer state; call it before the steps that matter are timed."""
         ops.TUNE_RECORD = {}
+        keep = self.ce_backward
         try:
-            self.forward_backward(features, captions, train=train)
+            for variant in ("loader", "pass"):  # both forms of the vocabulary projection's backward get their plans
+                self.ce_backward = variant
+                self.forward_backward(features, captions, train=train)
         finally:
             sigs, ops.TUNE_RECORD = ops.TUNE_RECORD, None
+            self.ce_backward = keep
         torch.cuda.synchronize()
-        return ops.tune_gemm_plans(sigs, verbose=verbose)
+        out = ops.tune_gemm_plans(sigs, verbose=verbose)
+        # ... and the faster of the two forms is kept (whole steps, timed with events on this stream)
+        times = {}
+        for variant in ("loader", "pass"):
+            self.ce_backward = variant
+            self.forward_backward(features, captions, train=train)
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+            for _ in range(3):
+                self.forward_backward(features, captions, train=train)
+            e1.record()
+            e1.synchronize()
+            times[variant] = e0.elapsed_time(e1) / 3
+        # the loader form (the block is written once, never rewritten) unless the pass form is clearly faster here
+        self.ce_backward = "pass" if times["pass"] < 0.98 * times["loader"] else "loader"
+        if verbose:
+            import sys
+            print(f"[capdec tune] vocabulary-projection backward: {times} ms per forward+backward -> {self.ce_backward}",
+                  file=sys.stderr, flush=True)
+        out["ce_backward"] = (self.ce_backward, times[self.ce_backward], times[keep if keep in times else "loader"])
+        return out
 
     def optimizer_step(self):
         self.step_count += 1

@@ -12,6 +12,9 @@ n = int(sys.argv[6]) if len(sys.argv) > 6 else 5
 a = torch.randn((K, M) if ta else (M, K), device="cuda")
 b = torch.randn((N, K) if tb else (K, N), device="cuda")
 out = torch.empty(M, N, device="cuda")
+kw = {}
+if os.environ.get("GEMM_CE"):  # the vocabulary projection as the trainer launches it: bias + cross-entropy partials
+    kw = dict(bias=torch.randn(N, device="cuda"), ce_partials=torch.empty(M, ops.ce_tiles(M, N, K), 4, device="cuda"))
 for _ in range(n):
-    ops.gemm(a, b, ta, tb, out=out)
+    ops.gemm(a, b, ta, tb, out=out, **kw)
 torch.cuda.synchronize()

@@ -188,7 +188,8 @@ def decode_bench(model, cfg, dev, rank, world, dtype="fp32", images=4096, max_le
 def mfma_peak(dtype):
     """Dense matrix peak in ALGORITHMIC (2*M*N*K) TFLOP/s: the split-fp32 mode issues six bf16 products per
     fp32 product, so its ceiling is the bf16 peak / 6."""
-    return {"fp32": PEAK_F32_MFMA_TFLOPS, "bf16": PEAK_BF16_MFMA_TFLOPS, "f32x3": PEAK_BF16_MFMA_TFLOPS / 6.0}[dtype]
+    return {"fp32": PEAK_F32_MFMA_TFLOPS, "bf16": PEAK_BF16_MFMA_TFLOPS, "bf16s": PEAK_BF16_MFMA_TFLOPS,
+            "f32x3": PEAK_BF16_MFMA_TFLOPS / 6.0}[dtype]
 
 
 def measured_mfma_peak(dtype):
@@ -318,7 +319,7 @@ def roofline_block(cfg, dtype, agg, detail, traffic=None, with_peaks=True):
     peak = mfma_peak(dtype)
     vk = f"gemm_nt_{cfg['batch'] * cfg['T']}x{cfg['vocab']}x{2 * cfg['d']}"
     vocab = detail.get(vk)
-    kname = {"fp32": "f32", "f32x3": "f32x3", "bf16": "bf16"}[dtype]
+    kname = {"fp32": "f32", "f32x3": "f32x3", "bf16": "bf16", "bf16s": "bf16s"}[dtype]
     roof = None
     if vocab:
         roof = {"bound": "mfma", "achieved": vocab[1] / vocab[3] / 1e12, "peak": peak, "unit": "TFLOP/s",
@@ -357,7 +358,9 @@ def run_leg(name, dtype, steps, warmup, dev, rank, world, args):
     agg, detail = profile_step(tr, feats, ids, reps=2)
     value = cfg["batch"] * world * steps / dt
     out = {"metric": "train_images_per_sec", "value": value, "unit": "images/s", "ms_per_step": dt / steps * 1e3,
-           "steps": steps, "warmup": warmup, "dtype": {"fp32": "f32", "f32x3": "f32x3", "bf16": "bf16 products, fp32 storage"}[dtype],
+           "steps": steps, "warmup": warmup, "dtype": {"fp32": "f32", "f32x3": "f32x3", "bf16": "bf16 products, fp32 storage",
+                                              "bf16s": "bf16 (products read bf16 copies of weights / activations / gradients; fp32 "
+                                                       "accumulate, norms, attention, loss, master weights and optimizer)"}[dtype],
            "loss": float(loss.item()), "params": tr.n_params,
            "config": {"workload": LEG_WORKLOADS[name], "global_batch": cfg["batch"] * world, "seq_len": cfg["T"],
                       "memory_len": cfg["S"]},
@@ -446,7 +449,7 @@ def main():
     ap.add_argument("--batch", type=int, default=0, help="per-GPU batch (default: the config's)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-dropout", action="store_true", help="eval-mode step (parity runs only; not the metric)")
-    ap.add_argument("--dtype", default="fp32", choices=["fp32", "f32x3", "bf16"],
+    ap.add_argument("--dtype", default="fp32", choices=["fp32", "f32x3", "bf16", "bf16s"],
                     help="fp32 = reference precision (the headline); bf16 = bf16 MFMA products, fp32 elsewhere")
     ap.add_argument("--no-decode", action="store_true")
     ap.add_argument("--no-side-streams", action="store_true", help="single-stream step (diagnostic)")
@@ -543,7 +546,7 @@ def main():
     legs = {}
     if args.config == "c2" and args.dtype == "fp32" and not args.no_legs and world == 1:
         legs["c1_fp32"] = run_leg("c1", "fp32", max(5, args.steps // 2), 3, dev, rank, world, args)
-        legs["c3_bf16"] = run_leg("c3", "bf16", max(5, args.steps // 2), 3, dev, rank, world, args)
+        legs["c3_bf16"] = run_leg("c3", "bf16s", max(5, args.steps // 2), 3, dev, rank, world, args)
     out = None
     if rank == 0:
         ms = dt / args.steps * 1e3
@@ -554,7 +557,7 @@ def main():
             "rccl_ranks": dist.get_world_size() if dist.is_initialized() else 1,
             "dist_backend": dist.get_backend() if dist.is_initialized() else None,
             "steps": args.steps, "warmup": args.warmup, "ms_per_step": ms, "higher_is_better": True,
-            "scaling": "weak", "vs_baseline": None, "dtype": {"fp32": "f32", "f32x3": "f32 (3 x bf16 split operands, six bf16 MFMA products)", "bf16": "bf16"}[args.dtype], "data": "synthetic",
+            "scaling": "weak", "vs_baseline": None, "dtype": {"fp32": "f32", "f32x3": "f32 (3 x bf16 split operands, six bf16 MFMA products)", "bf16": "bf16", "bf16s": "bf16"}[args.dtype], "data": "synthetic",
             "config": {"workload": f"BASELINE.json configs[1] (C2): 7x7x2048 grid features, hidden {cfg['d']}, "
                                    f"{cfg['layers']} layers, vocab {cfg['vocab']}, len {cfg['T']}, batch "
                                    f"{cfg['batch']}/GPU, teacher-forced train step incl. dropout, clip, AdamW"

@@ -11,7 +11,7 @@ import torch
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("CAPDEC_LIBRARY") or os.path.join(_HERE, "libcapdec.so")  # override: kernel experiments
 
-F32, BF16, F32X3 = 0, 1, 2
+F32, BF16, F32X3, BF16S = 0, 1, 2, 3
 ACT_NONE, ACT_GELU, ACT_GELU_BWD = 0, 1, 2
 
 _vp, _i, _f, _u64, _sz = C.c_void_p, C.c_int, C.c_float, C.c_uint64, C.c_size_t
@@ -42,6 +42,7 @@ SIGNATURES = {
     "capdec_layernorm_bwd_noalloc": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _f, _u64, _f,
                                           _u64, _vp]),
     "capdec_embed_fwd": (_i, [_vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _f, _u64, _vp]),
+    "capdec_embed_bad_ids": (_i, [C.POINTER(C.c_uint), _i]),
     "capdec_embed_bwd_workspace_bytes": (_sz, [_i, _i, _i, _i]),
     "capdec_embed_bwd": (_i, [_vp, _vp, _vp, _i, _i, _i, _i, _f, _u64, _vp, _sz, _vp]),
     "capdec_embed_bwd_plan": (_i, [_vp, _i, _i, _i, _i, _vp, _sz, _vp]),
@@ -53,6 +54,8 @@ SIGNATURES = {
     "capdec_gemm_ce_tiles": (_i, [_i, _i, _i, _i]),
     "capdec_ce_finalize": (_i, [_vp, _i, _vp, _i, _vp, _vp, _vp, _i, _i, _f, _vp]),
     "capdec_ce_dlogits": (_i, [_vp, _i, _vp, _vp, _i, _i, _f, _f, _vp]),
+    "capdec_cast_bf16": (_i, [_vp, _i, _vp, _i, _i, _i, _vp]),
+    "capdec_ce_dlogits_bf16": (_i, [_vp, _i, _vp, _vp, _i, _i, _f, _f, _vp, _i, _vp]),
     "capdec_reduce_workspace_bytes": (_sz, []),
     "capdec_sum": (_i, [_vp, _sz, _f, _vp, _vp, _sz, _vp]),
     "capdec_sumsq": (_i, [_vp, _sz, _vp, _vp, _sz, _vp]),

@@ -1,0 +1,89 @@
+// fp32 -> bf16 copies for the bf16-storage products (gemm_bf16s.hip).  ONE bf16 copy per tensor, in the tensor's own
+// orientation -- the GEMM reads either orientation, so nothing is transposed here: a matrix [R, C] (row stride lds
+// floats) becomes dst [R][ldd] bf16 with ldd a multiple of 8 >= C; the padding columns C .. ldd-1 are written as
+// zeros.  HBM-bound streaming kernels: 32 B in, 16 B out per thread step; round-to-nearest-even (the hardware's
+// v_cvt_pk_bf16_f32).
+//   capdec_cast_bf16        plain copy
+//   capdec_ce_dlogits_bf16  the label-smoothed cross-entropy gradient of a logits block, written straight to its
+//                           bf16 copy (ref train.py:41-50 backward): the fp32 dlogits matrix is never materialised
+#include "common.h"
+
+namespace capdec {
+
+typedef __bf16 bf16x8c __attribute__((ext_vector_type(8)));
+
+__device__ __forceinline__ void load8(const float* s, int c0, int C, bool vec, float (&v)[8]) {
+    if (vec && c0 + 8 <= C) {
+        const float4 a = *reinterpret_cast<const float4*>(s), b = *reinterpret_cast<const float4*>(s + 4);
+        v[0] = a.x; v[1] = a.y; v[2] = a.z; v[3] = a.w; v[4] = b.x; v[5] = b.y; v[6] = b.z; v[7] = b.w;
+    } else {
+#pragma unroll
+        for (int e = 0; e < 8; ++e) v[e] = c0 + e < C ? s[e] : 0.f;
+    }
+}
+
+__global__ __launch_bounds__(256) void cast_bf16_kernel(const float* __restrict__ src, int lds, __bf16* __restrict__ dst, int ldd,
+                                                         int R, int C, int vec) {
+    const int c8 = ldd / 8;  // 8-element groups per destination row
+    const size_t total = (size_t)R * c8;
+    for (size_t g = (size_t)blockIdx.x * 256 + threadIdx.x; g < total; g += (size_t)gridDim.x * 256) {
+        const int r = (int)(g / c8), c0 = (int)(g % c8) * 8;
+        float v[8];
+        load8(src + (size_t)r * lds + c0, c0, C, vec != 0, v);
+        bf16x8c o;
+#pragma unroll
+        for (int e = 0; e < 8; ++e) o[e] = (__bf16)v[e];
+        *reinterpret_cast<bf16x8c*>(dst + (size_t)r * ldd + c0) = o;
+    }
+}
+
+// one workgroup per logits row: dst[m][v] = gs * (exp(z - lse[m]) - eps/V - (1 - eps) * [v == y[m]])
+__global__ __launch_bounds__(256) void ce_dlogits_bf16_kernel(const float* __restrict__ z, int ldl, const float* __restrict__ lse_in,
+                                                               const int64_t* __restrict__ targets, int V, float eps, float gs,
+                                                               __bf16* __restrict__ dst, int ldd, int vec) {
+    const int m = blockIdx.x;
+    const float* zr = z + (size_t)m * ldl;
+    const float lse = lse_in[m], u = eps / (float)V, w = 1.f - eps;
+    int64_t y64 = targets[m];
+    const int y = (int)(y64 < 0 ? 0 : (y64 >= V ? V - 1 : y64));
+    for (int c0 = threadIdx.x * 8; c0 < ldd; c0 += 256 * 8) {
+        float v[8];
+        load8(zr + c0, c0, V, vec != 0, v);
+        bf16x8c o;
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+            float g = __expf(v[e] - lse) - u;
+            if (c0 + e == y) g -= w;
+            o[e] = (__bf16)(c0 + e < V ? g * gs : 0.f);
+        }
+        *reinterpret_cast<bf16x8c*>(dst + (size_t)m * ldd + c0) = o;
+    }
+}
+
+}  // namespace capdec
+
+using namespace capdec;
+
+extern "C" int capdec_cast_bf16(const void* src, int lds, void* dst, int ldd, int R, int C, capdec_stream_t stream) {
+    CAPDEC_REQUIRE(src && dst && R > 0 && C > 0 && lds >= C, "capdec_cast_bf16: bad arguments R=%d C=%d lds=%d", R, C, lds);
+    CAPDEC_REQUIRE(ldd % 8 == 0 && ldd >= C && aligned16(dst),
+                   "capdec_cast_bf16: ldd=%d must be a multiple of 8 that covers the row, dst 16-byte aligned", ldd);
+    const size_t groups = (size_t)R * (ldd / 8);
+    size_t blocks = (groups + 255) / 256;
+    if (blocks > 16384) blocks = 16384;
+    const int vec = aligned16(src) && lds % 4 == 0;
+    hipLaunchKernelGGL(cast_bf16_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, (const float*)src, lds,
+                       (__bf16*)dst, ldd, R, C, vec);
+    return check_launch("capdec_cast_bf16");
+}
+
+extern "C" int capdec_ce_dlogits_bf16(const void* logits, int ldl, const void* lse, const int64_t* targets, int M, int V,
+                                      float eps, float grad_scale, void* dst, int ldd, capdec_stream_t stream) {
+    CAPDEC_REQUIRE(logits && lse && targets && dst && M > 0 && V > 0 && ldl >= V, "capdec_ce_dlogits_bf16: bad arguments");
+    CAPDEC_REQUIRE(ldd % 8 == 0 && ldd >= V && aligned16(dst) && eps >= 0.f && eps < 1.f,
+                   "capdec_ce_dlogits_bf16: ldd=%d must be a multiple of 8 that covers V, dst 16-byte aligned, 0 <= eps < 1", ldd);
+    const int vec = aligned16(logits) && ldl % 4 == 0;
+    hipLaunchKernelGGL(ce_dlogits_bf16_kernel, dim3(M), dim3(256), 0, (hipStream_t)stream, (const float*)logits, ldl,
+                       (const float*)lse, targets, V, eps, grad_scale, (__bf16*)dst, ldd, vec);
+    return check_launch("capdec_ce_dlogits_bf16");
+}

@@ -4,7 +4,13 @@
 
 namespace capdec {
 
-// one wave per (b,t) row; float4 per lane; ids outside [0,V) are clamped (never dereferenced OOB).
+// Token ids outside [0, V) are clamped so that nothing is dereferenced out of bounds -- a guard, not semantics:
+// the reference raises there (nn.Embedding / scatter index errors, e.g. a checkpoint paired with another
+// vocabulary, ref main.py:113-137), so every clamped id is also COUNTED here and capdec_embed_bad_ids() hands the
+// count to the caller, who raises (the kernels themselves never synchronise).
+static __device__ unsigned int g_bad_ids;
+
+// one wave per (b,t) row; float4 per lane
 __global__ __launch_bounds__(256) void embed_fwd_kernel(const int64_t* __restrict__ ids, const float* __restrict__ E,
                                                          const float* __restrict__ pe, float* __restrict__ out, int BT,
                                                          int T, int d, int V, int t0, Dropout drop) {
@@ -12,6 +18,7 @@ __global__ __launch_bounds__(256) void embed_fwd_kernel(const int64_t* __restric
     const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
     if (row >= BT) return;
     int64_t id = ids[row];
+    if ((id < 0 || id >= V) && lane == 0) atomicAdd(&g_bad_ids, 1u);
     id = id < 0 ? 0 : (id >= V ? V - 1 : id);
     const int t = t0 + row % T;
     const float4* e4 = reinterpret_cast<const float4*>(E + (size_t)id * d);
@@ -214,6 +221,19 @@ extern "C" int capdec_embed_fwd(const int64_t* ids, const void* E, const void* p
     hipLaunchKernelGGL(embed_fwd_kernel, dim3((BT + 3) / 4), dim3(256), 0, (hipStream_t)stream, ids, (const float*)E,
                        (const float*)pe, (float*)out, BT, T, d, V, t0, make_dropout(drop_p, drop_seed));
     return check_launch("capdec_embed_fwd");
+}
+
+extern "C" int capdec_embed_bad_ids(unsigned int* count, int reset) {
+    CAPDEC_REQUIRE(count, "capdec_embed_bad_ids: null pointer");
+    if (hipMemcpyFromSymbol(count, HIP_SYMBOL(g_bad_ids), sizeof(unsigned int)) != hipSuccess) {
+        set_error("capdec_embed_bad_ids: hipMemcpyFromSymbol failed");
+        return CAPDEC_ERR_LAUNCH;
+    }
+    if (reset && *count) {
+        const unsigned int zero = 0;
+        if (hipMemcpyToSymbol(HIP_SYMBOL(g_bad_ids), &zero, sizeof(zero)) != hipSuccess) return CAPDEC_ERR_LAUNCH;
+    }
+    return CAPDEC_OK;
 }
 
 extern "C" size_t capdec_embed_bwd_workspace_bytes(int B, int T, int d, int V) {

@@ -212,5 +212,7 @@ GemmPlan plan_gemm_bf16(int M, int N, int K, const GemmForce& force);
 void launch_gemm_bf16(const GemmParams& p, const GemmPlan& pl, bool AK, bool BKM, bool vec, hipStream_t st);
 GemmPlan plan_gemm_f32x3(int M, int N, int K, const GemmForce& force);
 int launch_gemm_f32x3(const GemmParams& p, const GemmPlan& pl, bool AK, bool BKM, bool vec, hipStream_t st);
+GemmPlan plan_gemm_bf16s(int M, int N, int K, const GemmForce& force);
+void launch_gemm_bf16s(const GemmParams& p, const GemmPlan& pl, bool AKC, bool BKC, hipStream_t st);  // A, B: bf16
 
 }  // namespace capdec

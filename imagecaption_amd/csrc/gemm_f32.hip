@@ -374,7 +374,8 @@ static void launch_cfg(const GemmParams& p, bool AK, bool BKM, bool vec, dim3 gr
 using namespace capdec;
 
 extern "C" int capdec_gemm_tune(int bm, int bn, int split, int bk) {
-    const bool ok = ((bm == 0) || ((bm == 64 || bm == 128) && (bn == 64 || bn == 128) && split >= 1 && split <= 64)) &&
+    const bool ok = ((bm == 0) || (((bm == 64 || bm == 128) && (bn == 64 || bn == 128) || (bm == 256 && bn == 128)) &&
+                                   split >= 1 && split <= 64)) &&
                     (bk == 0 || bk == 16 || bk == 32);
     CAPDEC_REQUIRE(ok, "capdec_gemm_tune: unsupported tile %dx%d split %d bk %d", bm, bn, split, bk);
     g_gemm_force = GemmForce{bm, bn, split, bk};
@@ -391,9 +392,10 @@ static GemmPlan clamp_plan(GemmPlan pl, int M, int N, int K) {
 }
 
 static GemmPlan plan_for(int ta, int tb, int M, int N, int K, int dtype) {
-    const GemmForce f = resolve_force(ta, tb, M, N, K, dtype);
+    GemmForce f = resolve_force(ta, tb, M, N, K, dtype);
+    if (f.bm == 256 && dtype != CAPDEC_BF16S) f.bm = 128;  // the 256 x 128 tile exists for bf16 storage only
     return dtype == CAPDEC_BF16 ? plan_gemm_bf16(M, N, K, f) : dtype == CAPDEC_F32X3 ? plan_gemm_f32x3(M, N, K, f)
-                                                                                      : plan_gemm(M, N, K, f);
+           : dtype == CAPDEC_BF16S ? plan_gemm_bf16s(M, N, K, f) : plan_gemm(M, N, K, f);
 }
 
 extern "C" int capdec_gemm_ce_tiles(int M, int N, int K, int dtype) {
@@ -403,8 +405,8 @@ extern "C" int capdec_gemm_ce_tiles(int M, int N, int K, int dtype) {
 
 extern "C" int capdec_gemm_plan_set(int transA, int transB, int M, int N, int K, int dtype, int bm, int bn, int split,
                                     int bk) {
-    const bool ok = bm == 0 || ((bm == 64 || bm == 128) && (bn == 64 || bn == 128) && split >= 1 && split <= 64 &&
-                                (bk == 0 || bk == 16 || bk == 32));
+    const bool ok = bm == 0 || (((bm == 64 || bm == 128) && (bn == 64 || bn == 128) || (bm == 256 && bn == 128 && dtype == CAPDEC_BF16S)) &&
+                                split >= 1 && split <= 64 && (bk == 0 || bk == 16 || bk == 32));
     CAPDEC_REQUIRE(ok && M > 0 && N > 0 && K > 0, "capdec_gemm_plan_set: unsupported plan %dx%d split %d bk %d", bm, bn, split, bk);
     std::lock_guard<std::mutex> lock(g_plan_mu);
     if (bm == 0) g_plans.erase(plan_key(transA, transB, M, N, K, dtype));
@@ -422,7 +424,7 @@ extern "C" size_t capdec_gemm_workspace_bytes(int M, int N, int K) {
     size_t need = 0;  // the largest need over both transposes of either operand and the three compute types
     for (int ta = 0; ta < 2; ++ta)
         for (int tb = 0; tb < 2; ++tb)
-            for (int dtype : {CAPDEC_F32, CAPDEC_BF16, CAPDEC_F32X3}) {
+            for (int dtype : {CAPDEC_F32, CAPDEC_BF16, CAPDEC_F32X3, CAPDEC_BF16S}) {
                 const size_t b = splitk_workspace_bytes(clamp_plan(plan_for(ta, tb, M, N, K, dtype), M, N, K), M, N);
                 if (b > need) need = b;
             }
@@ -432,13 +434,17 @@ extern "C" size_t capdec_gemm_workspace_bytes(int M, int N, int K) {
 extern "C" int capdec_gemm(int transA, int transB, int M, int N, int K, const void* A, int lda, const void* B,
                            int ldb, void* C, int ldc, const capdec_epilogue* ep, int dtype, void* workspace,
                            size_t workspace_bytes, capdec_stream_t stream) {
-    CAPDEC_REQUIRE(dtype == CAPDEC_F32 || dtype == CAPDEC_BF16 || dtype == CAPDEC_F32X3,
+    CAPDEC_REQUIRE(dtype == CAPDEC_F32 || dtype == CAPDEC_BF16 || dtype == CAPDEC_F32X3 || dtype == CAPDEC_BF16S,
                    "capdec_gemm: dtype %d not supported", dtype);
     CAPDEC_REQUIRE(M > 0 && N > 0 && K > 0, "capdec_gemm: bad shape M=%d N=%d K=%d", M, N, K);
     CAPDEC_REQUIRE(A && B && C, "capdec_gemm: null operand");
     CAPDEC_REQUIRE(lda >= (transA ? M : K) && ldb >= (transB ? K : N) && ldc >= N,
                    "capdec_gemm: leading dimension too small (lda=%d ldb=%d ldc=%d)", lda, ldb, ldc);
-    CAPDEC_REQUIRE((uint64_t)M * (uint64_t)N < (1ull << 32), "capdec_gemm: M*N exceeds 2^32 (dropout index)");
+    // the epilogue's dropout mask is indexed by the 32-bit element number m*N + n: only products WITH dropout are bound
+    // by it (the vocabulary projection has none and is the largest M*N of the path)
+    CAPDEC_REQUIRE(!(ep && ep->drop_p > 0.f) || (uint64_t)M * (uint64_t)N < (1ull << 32),
+                   "capdec_gemm: M*N exceeds 2^32 with dropout in the epilogue (32-bit mask index)");
+    CAPDEC_REQUIRE((uint64_t)cdiv(M, 64) * (uint64_t)cdiv(N, 64) < (1ull << 31), "capdec_gemm: too many tiles");
     GemmParams p;
     memset(&p, 0, sizeof(p));
     p.A = (const float*)A;
@@ -496,11 +502,22 @@ extern "C" int capdec_gemm(int transA, int transB, int M, int N, int K, const vo
     p.tiles_n = cdiv(N, pl.bn);
     const bool vec = aligned16(A) && aligned16(B) && (lda % 4 == 0) && (ldb % 4 == 0);
     const bool AK = !transA, BKM = transB != 0;
+    if (dtype == CAPDEC_BF16S) {
+        // bf16 operands move in 16-byte pieces of 8 elements: pitches are multiples of 8 that cover the contiguous
+        // extent ROUNDED UP to 8 (a piece that straddles the edge is read whole and masked in registers)
+        const int ea = (transA ? M : K), eb = (transB ? K : N);
+        CAPDEC_REQUIRE(aligned16(A) && aligned16(B) && lda % 8 == 0 && ldb % 8 == 0 && lda >= (ea + 7) / 8 * 8 && ldb >= (eb + 7) / 8 * 8,
+                       "capdec_gemm: CAPDEC_BF16S operands are bf16 matrices, 16-byte aligned, with leading dimensions "
+                       "that are multiples of 8 and cover the row rounded up to 8 (lda=%d ldb=%d)", lda, ldb);
+        CAPDEC_REQUIRE(!p.ce_lse, "capdec_gemm: CAPDEC_BF16S takes dlogits from capdec_ce_dlogits_bf16, not ce_lse");
+    }
     CAPDEC_REQUIRE(!p.ce_lse || (vec && !BKM), "capdec_gemm: ce_lse needs transB = 0 and 16-byte aligned operands with "
                                                "leading dimensions that are multiples of 4");
     dim3 grid(cdiv(M, pl.bm) * p.tiles_n, 1, pl.split);
     hipStream_t st = (hipStream_t)stream;
-    if (dtype == CAPDEC_BF16) {
+    if (dtype == CAPDEC_BF16S) {
+        launch_gemm_bf16s(p, pl, AK, BKM, st);
+    } else if (dtype == CAPDEC_BF16) {
         launch_gemm_bf16(p, pl, AK, BKM, vec, st);
     } else if (dtype == CAPDEC_F32X3) {
         const int lrc = launch_gemm_f32x3(p, pl, AK, BKM, vec, st);

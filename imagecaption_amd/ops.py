@@ -14,21 +14,67 @@ from . import _capi
 from ._capi import ACT_GELU_BWD, ACT_NONE, F32, check, lib, ptr, stream
 
 __all__ = ["compute_dtype", "gemm", "linear_fwd", "linear_dgrad", "linear_wgrad", "layernorm_fwd", "layernorm_bwd", "embed_fwd",
-           "embed_bwd", "attn_fwd", "attn_bwd", "softmax_ce", "ce_tiles", "ce_finalize", "ce_dlogits", "reduce_sum", "sumsq", "adamw", "clip_scale", "pe_add",
+           "embed_bwd", "attn_fwd", "attn_bwd", "softmax_ce", "ce_tiles", "ce_finalize", "ce_dlogits", "ce_dlogits_bf16", "cast_bf16", "reduce_sum", "sumsq", "adamw", "clip_scale", "pe_add",
            "act_dropout_bwd"]
 
 
 # Arithmetic type of the matrix products.  F32: exact fp32 MFMA (reference precision, the default).
 # BF16: operands rounded to bf16 on load, bf16 MFMA, fp32 accumulation / epilogue / storage
 # ("autocast"-style mixed precision; tolerances are stated separately in the tests).
+# BF16S: the same arithmetic on bf16 COPIES of the operands (capdec_cast_bf16): the products read half the bytes and
+# convert nothing; results, epilogues, norms, attention, loss and optimizer state stay fp32.
 COMPUTE_DTYPE = F32
+
+# bf16 copies made during one training step: (data_ptr, rows, cols, row stride) -> (source, copy).  None = off: every
+# product casts its operands afresh.  Only a caller that knows when tensors change may switch it on (CaptionTrainer:
+# a dict per step, dropped at the step's end -- weights change in the optimizer, buffers are reused by the next step);
+# holding the source keeps its memory from being handed to another tensor while the entry lives.
+BF16_MEMO = None
+
+
+def _bf16_pitch(cols):
+    """Row stride (elements) of a bf16 copy: a multiple of 8 covering the row; a pitch that is a multiple of 1 KiB
+    would put every row of a GEMM tile on the same few L2 / HBM channels, so such pitches get one more 128-byte line."""
+    ldd = (cols + 7) // 8 * 8
+    if os.environ.get("CAPDEC_BF16_NOPAD") is None and ldd % 512 == 0:
+        ldd += 64
+    return ldd
+
+
+def cast_bf16(t):
+    """bf16 copy of an fp32 matrix (row-strided views welcome): [R, C] view of a [R, round_up(C, 8)] buffer whose
+    padding columns are zero -- the form capdec_gemm's CAPDEC_BF16S operands take, in either orientation."""
+    _mat(t, "cast_bf16.src")
+    R, Cc = t.shape
+    ldd = _bf16_pitch(Cc)
+    dst = torch.empty((R, ldd), dtype=torch.bfloat16, device=t.device)
+    check(lib().capdec_cast_bf16(ptr(t), t.stride(0), ptr(dst), ldd, R, Cc, stream()), "capdec_cast_bf16")
+    return dst[:, :Cc]
+
+
+def _bf16_operand(t, name):
+    if t.dtype == torch.bfloat16:
+        if not t.is_cuda or t.dim() != 2 or t.stride(1) != 1 or t.stride(0) % 8 or t.stride(0) < (t.shape[1] + 7) // 8 * 8 \
+                or t.data_ptr() % 16:
+            raise _capi.CapdecError(f"{name}: a bf16 operand must be a 16-byte aligned 2-D view with unit column stride and a "
+                                    f"row stride that is a multiple of 8 covering the row rounded up to 8 (ops.cast_bf16 makes "
+                                    f"one), got {tuple(t.shape)} / {t.stride()}")
+        return t
+    if BF16_MEMO is None:
+        return cast_bf16(t)
+    key = (t.data_ptr(), t.shape[0], t.shape[1], t.stride(0))
+    hit = BF16_MEMO.get(key)
+    if hit is None:
+        hit = BF16_MEMO[key] = (t, cast_bf16(t))
+    return hit[1]
 
 
 class compute_dtype:
     """with ops.compute_dtype("bf16"): ...  -- scoped override of COMPUTE_DTYPE."""
 
     def __init__(self, name):
-        self.value = {"f32": F32, "fp32": F32, "bf16": _capi.BF16, "f32x3": _capi.F32X3, "fp32x3": _capi.F32X3}[str(name).lower()]
+        self.value = {"f32": F32, "fp32": F32, "bf16": _capi.BF16, "f32x3": _capi.F32X3, "fp32x3": _capi.F32X3,
+                      "bf16s": _capi.BF16S}[str(name).lower()]
 
     def __enter__(self):
         global COMPUTE_DTYPE
@@ -188,7 +234,7 @@ _TUNED = {}         # the same key -> (bm, bn, split, bk) already pinned in this
 
 def _plan_candidates(dtype, M, N, K):
     tiles_by = {F32: [(128, 128), (128, 64), (64, 128), (64, 64)], _capi.BF16: [(128, 128), (64, 64)],
-                _capi.F32X3: [(128, 128), (128, 64), (64, 64)]}[dtype]
+                _capi.F32X3: [(128, 128), (128, 64), (64, 64)], _capi.BF16S: [(256, 128), (128, 128), (64, 64)]}[dtype]
     bks = (16, 32) if dtype == F32 else (0,)
     for bm, bn in tiles_by:
         tiles = -(-M // bm) * -(-N // bn)
@@ -223,8 +269,10 @@ def tune_gemm_plans(signatures, reps=4, min_gain=0.03, verbose=False):
                 continue
             ta, tb, M, N, K, dtype = key
             dev = torch.device("cuda", torch.cuda.current_device())
-            a = torch.randn((K if ta else M, lda), device=dev)[:, :(M if ta else K)]
-            b = torch.randn((N if tb else K, ldb), device=dev)[:, :(K if tb else N)]
+            a, b = torch.randn((K if ta else M, lda), device=dev), torch.randn((N if tb else K, ldb), device=dev)
+            if dtype == _capi.BF16S:  # the recorded strides are those of the bf16 copies
+                a, b = a.to(torch.bfloat16), b.to(torch.bfloat16)
+            a, b = a[:, :(M if ta else K)], b[:, :(K if tb else N)]
             c = torch.empty((M, ldc), device=dev)[:, :N]
             ce = None
             if has_ce:  # the loaders that turn logits into dlogits are their own instantiation: time THAT kernel
@@ -265,7 +313,12 @@ def gemm(a, b, trans_a, trans_b, out=None, bias=None, addend=None, pre=None, aux
     ``ce_partials``: [M, ce_tiles(M, N, K)] x 4 floats receiving the per-tile softmax partials of the logits this
     product writes (fused cross-entropy, forward).  ``ce = (lse, targets, eps, grad_scale)``: ``a`` holds LOGITS and
     is read as dlogits (fused cross-entropy, backward; exact-fp32 compute type only)."""
-    _mat(a, "gemm.a"), _mat(b, "gemm.b")
+    if COMPUTE_DTYPE == _capi.BF16S:
+        if ce is not None:
+            raise _capi.CapdecError("gemm: the bf16-storage products take dlogits from ops.ce_dlogits_bf16, not ce=")
+        a, b = _bf16_operand(a, "gemm.a"), _bf16_operand(b, "gemm.b")
+    else:
+        _mat(a, "gemm.a"), _mat(b, "gemm.b")
     M, K = (a.shape[1], a.shape[0]) if trans_a else (a.shape[0], a.shape[1])
     Kb, N = (b.shape[1], b.shape[0]) if trans_b else (b.shape[0], b.shape[1])
     if K != Kb:
@@ -336,6 +389,8 @@ def linear_wgrad(dy, x, dw=None, db=None, ce=None):
     With a SideStream active and caller-owned outputs, the product is enqueued on the side stream
     (ordered after everything enqueued so far on the current stream) and the call returns at once."""
     if SIDE is not None and dw is not None:
+        if COMPUTE_DTYPE == _capi.BF16S:  # bf16 copies are made (or found) on the caller's stream, not on the lane
+            dy, x = _bf16_operand(dy, "linear_wgrad.dy"), _bf16_operand(x, "linear_wgrad.x")
         SIDE.run(lambda: gemm(dy, x, True, False, out=dw, colsum=db, ce=ce), dy, x)
         return dw
     return gemm(dy, x, True, False, out=dw, colsum=db, ce=ce)
@@ -397,6 +452,17 @@ def embed_fwd(ids, E, pe, t0=0, drop_p=0.0, seed=0):
     check(lib().capdec_embed_fwd(ptr(ids), ptr(_req(E, "embed.E")), ptr(_req(pe, "embed.pe")), ptr(out), B, T, d, V,
                                  int(t0), float(drop_p), int(seed), stream()), "capdec_embed_fwd")
     return out
+
+
+def check_ids():
+    """Raise IndexError if any token id given to embed_fwd on the current device since the last check was outside
+    [0, V): the kernels clamp such ids (an out-of-bounds guard), the reference's nn.Embedding raises.  Synchronises."""
+    n = C.c_uint(0)
+    check(lib().capdec_embed_bad_ids(C.byref(n), 1), "capdec_embed_bad_ids")
+    if n.value:
+        raise IndexError(f"{n.value} token id(s) outside the vocabulary were given to the embedding since the last check "
+                         "(clamped on the device; the reference raises an index error: is the dataset's vocabulary the "
+                         "checkpoint's?)")
 
 
 def embed_bwd_workspace(B, T, d, V, device):
@@ -542,6 +608,21 @@ def ce_dlogits(logits, lse, targets, eps, grad_scale):
                                   ptr(_req(targets, "ce_dlogits.targets", torch.int64).contiguous()), M, V, float(eps),
                                   float(grad_scale), stream()), "capdec_ce_dlogits")
     return logits
+
+
+def ce_dlogits_bf16(logits, lse, targets, eps, grad_scale):
+    """The label-smoothed cross-entropy gradient of a logits block as a bf16 matrix (the operand form of the
+    bf16-storage products); the fp32 logits are left as they are."""
+    _mat(logits, "ce_dlogits_bf16.logits")
+    rows, V = logits.shape
+    if _req(lse, "ce_dlogits_bf16.lse").numel() != rows or _req(targets, "ce_dlogits_bf16.targets", torch.int64).numel() != rows \
+            or not (lse.is_contiguous() and targets.is_contiguous()):
+        raise _capi.CapdecError("ce_dlogits_bf16: lse / targets must be contiguous with one entry per logits row")
+    ldd = _bf16_pitch(V)
+    dst = torch.empty((rows, ldd), dtype=torch.bfloat16, device=logits.device)
+    check(lib().capdec_ce_dlogits_bf16(ptr(logits), logits.stride(0), ptr(lse), ptr(targets), rows, V, float(eps),
+                                        float(grad_scale), ptr(dst), ldd, stream()), "capdec_ce_dlogits_bf16")
+    return dst[:, :V]
 
 
 def reduce_sum(x, scale=1.0):

@@ -69,7 +69,9 @@ class CaptionTrainer:
         # streaming pass turns the block into dlogits first.  tune() measures both and keeps the faster.
         self.ce_backward = ce_backward
         # "fp32" (exact fp32 MFMA, the reference's precision), "f32x3" (split-bf16 products, fp32-level accuracy)
-        # or "bf16" (bf16 MFMA products, fp32 everything else)
+        # "bf16" (bf16 MFMA products on fp32 operands rounded in the loaders, fp32 everything else) or "bf16s" (bf16
+        # STORAGE: the products read bf16 copies of weights / activations / gradients, made once per tensor and step;
+        # fp32 accumulation, results, norms, attention, loss, master weights and optimizer)
         self.dtype = dtype
         self.world = dist.get_world_size(process_group) if (dist.is_available() and dist.is_initialized()) else 1
         self.rank = dist.get_rank(process_group) if self.world > 1 else 0
@@ -138,6 +140,9 @@ class CaptionTrainer:
     # ---- one iteration of ref train.py:24-61 ---------------------------------------------------------
     def forward_backward(self, features, captions, train=True, keep_logits=False):
         prev, ops.SIDE = ops.SIDE, self.side
+        # bf16 storage: one bf16 copy per tensor and step (weights, activations, gradients), shared by the forward,
+        # input-gradient and weight-gradient products that read it; dropped when the step's kernels are enqueued
+        memo, ops.BF16_MEMO = ops.BF16_MEMO, ({} if self.dtype == "bf16s" else None)
         try:
             with ops.compute_dtype(self.dtype):
                 return self._forward_backward(features, captions, train, keep_logits)
@@ -145,6 +150,7 @@ class CaptionTrainer:
             if self.side is not None:
                 self.side.join()
             ops.SIDE = prev
+            ops.BF16_MEMO = memo
 
     def _forward_backward(self, features, captions, train, keep_logits):
         m = self.model
@@ -197,7 +203,9 @@ class CaptionTrainer:
         loss = ops.reduce_sum(rows, 1.0 / (B * T))
         nb = len(self.bucket_ranges)
         ce = (lse, targets, self.smooth, 1.0 / (B * T * self.world))
-        if self.dtype != "fp32" or V % 4 or self.ce_backward == "pass":  # the loader transform: exact fp32, float4 loaders
+        if self.dtype == "bf16s":  # the gradient goes straight to the bf16 copy both backward products read
+            logits, ce = ops.ce_dlogits_bf16(logits, *ce), None
+        elif self.dtype != "fp32" or V % 4 or self.ce_backward == "pass":  # the loader transform: exact fp32, float4 loaders
             ops.ce_dlogits(logits, *ce)
             ce = None
         dy = engine.head_bwd(self.P_head, self.G_head, sv_head, logits, dp, ce=ce)
@@ -227,8 +235,10 @@ class CaptionTrainer:
         Changes no parameter and no optimizer state; call it before the steps that matter are timed."""
         ops.TUNE_RECORD = {}
         keep = self.ce_backward
+        V = self.P_head["3.weight"].shape[0]
+        variants = ("loader", "pass") if self.dtype == "fp32" and V % 4 == 0 else (keep,)  # others have one form
         try:
-            for variant in ("loader", "pass"):  # both forms of the vocabulary projection's backward get their plans
+            for variant in variants:  # both forms of the vocabulary projection's backward get their plans
                 self.ce_backward = variant
                 self.forward_backward(features, captions, train=train)
         finally:
@@ -238,7 +248,10 @@ class CaptionTrainer:
         out = ops.tune_gemm_plans(sigs, verbose=verbose)
         # ... and the faster of the two forms is kept (whole steps, timed with events on this stream)
         times = {}
-        for variant in ("loader", "pass"):
+        if len(variants) == 1:
+            self.ce_backward = keep
+            return out
+        for variant in variants:
             self.ce_backward = variant
             self.forward_backward(features, captions, train=train)
             e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
@@ -256,6 +269,11 @@ class CaptionTrainer:
                   file=sys.stderr, flush=True)
         out["ce_backward"] = (self.ce_backward, times[self.ce_backward], times[keep if keep in times else "loader"])
         return out
+
+    def check_ids(self):
+        """Raise IndexError if a step since the last call saw token ids outside the vocabulary (synchronises: call it
+        once per epoch or per logging interval, not per step)."""
+        ops.check_ids()
 
     def optimizer_step(self):
         self.step_count += 1

@@ -30,12 +30,16 @@ extern "C" {
 typedef void* capdec_stream_t; /* hipStream_t */
 
 enum { CAPDEC_OK = 0, CAPDEC_ERR_ARG = -1, CAPDEC_ERR_LAUNCH = -2, CAPDEC_ERR_UNSUPPORTED = -3, CAPDEC_ERR_WORKSPACE = -4 };
-/* compute type of capdec_gemm (storage is fp32 in all three):
+/* compute type of capdec_gemm (operands and results are fp32 in memory in the first three):
  *   CAPDEC_F32   exact fp32 MFMA (v_mfma_f32_32x32x2_f32)
  *   CAPDEC_BF16  operands rounded to bf16, fp32 accumulate (mixed precision)
  *   CAPDEC_F32X3 fp32 operands split exactly into 3 bf16 terms, 6 bf16 MFMA partial products, fp32
- *                accumulate: fp32-level accuracy at 2.7x the fp32 matrix rate (csrc/gemm_f32x3.hip) */
-enum { CAPDEC_F32 = 0, CAPDEC_BF16 = 1, CAPDEC_F32X3 = 2 };
+ *                accumulate: fp32-level accuracy at 2.7x the fp32 matrix rate (csrc/gemm_f32x3.hip)
+ *   CAPDEC_BF16S bf16 STORAGE: A and B point to bf16 matrices (made by capdec_cast_bf16 /
+ *                capdec_ce_dlogits_bf16), either transpose; 16-byte aligned, lda / ldb multiples of 8 that cover
+ *                the row rounded up to 8; bf16 MFMA, fp32 accumulate, fp32 epilogue and result
+ *                (csrc/gemm_bf16s.hip).  ce_lse is not available (use capdec_ce_dlogits_bf16). */
+enum { CAPDEC_F32 = 0, CAPDEC_BF16 = 1, CAPDEC_F32X3 = 2, CAPDEC_BF16S = 3 };
 enum { CAPDEC_ACT_NONE = 0, CAPDEC_ACT_GELU = 1, CAPDEC_ACT_GELU_BWD = 2 };
 
 int capdec_abi_version(void);
@@ -89,7 +93,8 @@ typedef struct capdec_epilogue {
  * entry point writes to, and never share one workspace between GEMMs that may run concurrently on two streams). */
 #define CAPDEC_GEMM_TICKET_BYTES 16384
 size_t capdec_gemm_workspace_bytes(int M, int N, int K);
-/* Tuning hook (process-global, not thread-safe): force block tile bm x bn in {64,128}^2 and a split-K
+/* Tuning hook (process-global, not thread-safe): force block tile bm x bn in {64,128}^2 (CAPDEC_BF16S: 64 x 64,
+ * 128 x 128 or 256 x 128; other compute types run a forced 256 x 128 as 128 x 128) and a split-K
  * factor (and k-tile bk in {0 = default, 16, 32}) for every following capdec_gemm call; bm = 0
  * restores the built-in cost model. */
 int capdec_gemm_tune(int bm, int bn, int split, int bk);
@@ -103,6 +108,20 @@ void capdec_gemm_plan_clear(void);
 int capdec_gemm(int transA, int transB, int M, int N, int K, const void* A, int lda, const void* B, int ldb,
                 void* C, int ldc, const capdec_epilogue* ep, int dtype, void* workspace, size_t workspace_bytes,
                 capdec_stream_t stream);
+
+/* ---- bf16 copies for CAPDEC_BF16S products ----------------------------------------------------------------
+ * capdec_cast_bf16: dst[r][c] = bf16(src[r][c]) (round to nearest even) for an fp32 matrix [R, C] with row stride
+ * lds; dst has row stride ldd (bf16 elements, a multiple of 8, >= C) and its padding columns C .. ldd-1 are
+ * written as zeros.  One copy per tensor serves every product that reads it: capdec_gemm reads bf16 operands in
+ * either orientation.  Replaces the .to(bfloat16) casts torch.autocast inserts around F.linear
+ * (torch/amp/autocast_mode.py) if the reference's train.py:255-330 loop is run under bf16 autocast (BASELINE.json
+ * configs[2]); the reference itself trains in fp32.
+ * capdec_ce_dlogits_bf16: the label-smoothed cross-entropy gradient (ref train.py:41-50 backward) of a logits
+ * block [M, V] written directly as its bf16 copy: dst[m][v] = bf16(grad_scale * (exp(z - lse[m]) - eps/V -
+ * (1 - eps) * [v == targets[m]])), padding columns zero; lse from capdec_ce_finalize. */
+int capdec_cast_bf16(const void* src, int lds, void* dst, int ldd, int R, int C, capdec_stream_t stream);
+int capdec_ce_dlogits_bf16(const void* logits, int ldl, const void* lse, const int64_t* targets, int M, int V,
+                           float eps, float grad_scale, void* dst, int ldd, capdec_stream_t stream);
 
 /* ---- LayerNorm (+ optional GELU + dropout) ----------------------------------------------------
  * fwd: y = dropout(act(LN(x))), LN eps as given; mean/rstd [M] saved for backward (may be NULL).
@@ -154,6 +173,11 @@ int capdec_layernorm_bwd_noalloc(const void* dy, const void* x, const void* gamm
  */
 int capdec_embed_fwd(const int64_t* ids, const void* E, const void* pe, void* out, int B, int T, int d, int V,
                      int t0, float drop_p, uint64_t drop_seed, capdec_stream_t stream);
+/* Token ids outside [0, V) are clamped by the kernels (an out-of-bounds guard) and counted: *count receives the
+ * number of clamped ids that capdec_embed_fwd launches on the current device have seen since the last reset (this
+ * call synchronises the device).  The reference raises an index error in that case; so does the Python layer
+ * (CaptionTrainer.check_ids / ops.check_ids). */
+int capdec_embed_bad_ids(unsigned int* count, int reset);
 size_t capdec_embed_bwd_workspace_bytes(int B, int T, int d, int V);
 int capdec_embed_bwd(const int64_t* ids, const void* dout, void* dE, int B, int T, int d, int V, float drop_p,
                      uint64_t drop_seed, void* workspace, size_t workspace_bytes, capdec_stream_t stream);

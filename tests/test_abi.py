@@ -29,6 +29,12 @@ def test_argument_errors_are_reported_without_a_gpu():
     assert b"capdec_gemm" in lib.capdec_last_error()
     assert lib.capdec_attn_fwd(None, 0, None, 0, None, 0, None, 0, None, 1, 1, 4, 4, 48, 0, 1.0, 0.0, 0, None) == -1
     assert b"head dim" in lib.capdec_last_error()
+    # M*N >= 2^32 is refused only when the epilogue has dropout (32-bit mask index); here: refused for the null operands
+    ep = _capi.Epilogue()
+    ep.drop_p = 0.1
+    import ctypes as C
+    assert lib.capdec_gemm(0, 1, 1 << 17, 1 << 15, 8, 16, 8, 16, 8, 16, 1 << 15, C.byref(ep), 0, None, 0, None) == -1
+    assert b"dropout" in lib.capdec_last_error()
     assert lib.capdec_gemm_workspace_bytes(512, 512, 5120) > 0
     assert lib.capdec_gemm_workspace_bytes(5120, 10000, 1024) == 0
 

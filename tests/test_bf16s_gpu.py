@@ -1,0 +1,193 @@
+"""bf16-STORAGE products (CAPDEC_BF16S, BASELINE.json configs[2] "bf16 training"): the cast kernels, the GEMM that
+reads bf16 operands in either orientation, and the fused cross-entropy pieces around it.
+
+Oracle here: the same product computed in float64 ON THE bf16-ROUNDED OPERANDS (torch's .to(bfloat16) is
+round-to-nearest-even, as the cast kernel is) -- so the only difference left is fp32 accumulation order, and the
+tolerance is the fp32 one (2e-6 * sqrt(K)), not a loose "bf16 tolerance".  The bf16-vs-fp32 MODEL tolerances
+(2e-2 logits / 5e-3 loss / 6e-2 gradients) are stated where the whole model is compared (test_model_gpu.py).
+"""
+import math
+
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+DEV = "cuda"
+
+
+def _ops():
+    from imagecaption_amd import ops
+    return ops
+
+
+def relerr(a, b):
+    a, b = a.detach().double().cpu(), b.detach().double().cpu()
+    return float((a - b).abs().max() / (b.abs().max() + 1e-30))
+
+
+def r16(t):
+    return t.to(torch.bfloat16).double()
+
+
+def gelu(x):
+    return 0.5 * x * (1 + torch.erf(x / math.sqrt(2)))
+
+
+@pytest.mark.parametrize("R,C,pad", [(1, 1, 0), (3, 7, 0), (5, 8, 3), (33, 100, 5), (257, 1024, 0), (64, 30001, 0)])
+def test_cast_is_round_to_nearest_even_with_zero_padding(R, C, pad):
+    ops = _ops()
+    g = torch.Generator().manual_seed(R * 31 + C)
+    full = torch.randn(R, C + pad, generator=g) * 3
+    full[0, 0] = 1.00390625  # 1 + 2^-8: a tie, rounds to even (1.0)
+    src = full.to(DEV)[:, :C]  # a row-strided view when pad > 0
+    out = ops.cast_bf16(src)
+    assert out.dtype == torch.bfloat16 and tuple(out.shape) == (R, C) and out.stride(0) % 8 == 0
+    assert torch.equal(out.cpu(), full[:, :C].to(torch.bfloat16))
+    ldd = out.stride(0)
+    whole = torch.as_strided(out, (R, ldd), (ldd, 1))
+    assert torch.all(whole[:, C:] == 0)
+
+
+@pytest.mark.parametrize("M,N,K", [(1, 1, 4), (3, 50, 24), (37, 108, 64), (129, 257, 100), (256, 512, 512),
+                                    (300, 1000, 130), (5120, 128, 64), (64, 64, 2048), (70, 70, 5125), (131, 77, 9)])
+@pytest.mark.parametrize("ta,tb", [(0, 1), (0, 0), (1, 0), (1, 1)])
+def test_gemm_reads_bf16_operands_in_either_orientation(M, N, K, ta, tb):
+    ops = _ops()
+    g = torch.Generator().manual_seed(M * 7 + N * 3 + K + ta * 2 + tb)
+    a = torch.randn((K, M) if ta else (M, K), generator=g)
+    b = torch.randn((N, K) if tb else (K, N), generator=g)
+    ref = (r16(a).T if ta else r16(a)) @ (r16(b).T if tb else r16(b))
+    from imagecaption_amd import _capi
+    l = _capi.lib()
+    with ops.compute_dtype("bf16s"):
+        out = ops.gemm(a.to(DEV), b.to(DEV), ta, tb)                                  # fp32 operands: cast inside
+        out2 = ops.gemm(ops.cast_bf16(a.to(DEV)), ops.cast_bf16(b.to(DEV)), ta, tb)   # bf16 operands as given
+        try:  # the large tile (one LDS image, 128 x 64 per wave) on the same ragged shapes
+            l.capdec_gemm_tune(256, 128, 1, 0)
+            out3 = ops.gemm(a.to(DEV), b.to(DEV), ta, tb)
+        finally:
+            l.capdec_gemm_tune(0, 0, 0, 0)
+    assert out.dtype == torch.float32
+    assert relerr(out, ref) < 2e-6 * math.sqrt(K)
+    assert torch.equal(out, out2)
+    assert relerr(out3, ref) < 2e-6 * math.sqrt(K)
+
+
+def test_gemm_asymmetric_identity_all_layouts():
+    """A = I with an asymmetric B catches swapped row / column maps and a wrong register transpose (values are small
+    integers: exact in bf16)."""
+    ops = _ops()
+    n = 136
+    b = ((torch.arange(n * n, dtype=torch.float32).reshape(n, n) % 251) - 100.0)
+    eye = torch.eye(n, device=DEV)
+    with ops.compute_dtype("bf16s"):
+        assert torch.equal(ops.gemm(eye, b.to(DEV), 0, 0).cpu(), b)
+        assert torch.equal(ops.gemm(eye, b.to(DEV), 0, 1).cpu(), b.T)
+        assert torch.equal(ops.gemm(b.to(DEV), eye, 0, 0).cpu(), b)
+        assert torch.equal(ops.gemm(b.to(DEV), eye, 1, 0).cpu(), b.T)
+        assert torch.equal(ops.gemm(b.to(DEV), eye, 1, 1).cpu(), b.T)
+        assert torch.equal(ops.gemm(eye, b.to(DEV), 1, 1).cpu(), b.T)
+
+
+def test_forced_plans_splitk_epilogue_and_bias_gradient():
+    ops = _ops()
+    from imagecaption_amd import _capi
+    from imagecaption_amd._capi import ACT_GELU
+    l = _capi.lib()
+    g = torch.Generator().manual_seed(5)
+    try:
+        with ops.compute_dtype("bf16s"):
+            for (M, N, K) in ((200, 136, 1100), (512, 512, 5120), (70, 64, 2048)):
+                x, w = torch.randn(M, K, generator=g), torch.randn(N, K, generator=g) / 8
+                b, r = torch.randn(N, generator=g), torch.randn(M, N, generator=g)
+                dy, a2 = torch.randn(K, M, generator=g), torch.randn(K, N, generator=g)
+                want = gelu(r16(x) @ r16(w).T + b.double()) + r.double()
+                want_tn = r16(dy).T @ r16(a2)
+                want_cs = r16(dy).sum(0)
+                xs, ws_, bs, rs, dys, a2s = (t.to(DEV) for t in (x, w, b, r, dy, a2))
+                for bm, split in ((64, 1), (64, 4), (128, 2), (128, 1), (64, 16), (128, 8), (256, 1), (256, 4)):
+                    l.capdec_gemm_tune(bm, min(bm, 128), split, 0)
+                    ops._WS_NEED.clear()
+                    outs = []
+                    for _ in range(2):
+                        o = ops.linear_fwd(xs, ws_, bs, act=ACT_GELU, addend=rs)
+                        cs = torch.empty(M, device=DEV)
+                        o2 = ops.gemm(dys, a2s, True, False, colsum=cs)
+                        outs.append((o, o2, cs))
+                    assert relerr(outs[0][0], want) < 2e-5, (M, N, K, bm, split)
+                    assert relerr(outs[0][1], want_tn) < 2e-5 and relerr(outs[0][2], want_cs) < 2e-5, (M, N, K, bm, split)
+                    for p, q in zip(outs[0], outs[1]):
+                        assert torch.equal(p, q), (M, N, K, bm, split)
+    finally:
+        l.capdec_gemm_tune(0, 0, 0, 0)
+        ops._WS_NEED.clear()
+
+
+@pytest.mark.parametrize("rows,V,K", [(96, 1000, 64), (200, 30001, 72), (37, 257, 40)])
+def test_cross_entropy_around_the_bf16_vocabulary_product(rows, V, K):
+    """Forward: the product's epilogue leaves the softmax partials (as in the fp32 path); backward: the gradient is
+    written straight to its bf16 copy and both backward products read that copy."""
+    ops = _ops()
+    g = torch.Generator().manual_seed(rows + V)
+    eps = 0.1
+    h, w, b = torch.randn(rows, K, generator=g), torch.randn(V, K, generator=g) / 4, torch.randn(V, generator=g)
+    y = torch.randint(0, V, (rows,), generator=g)
+    y[::7] = 0  # pad targets are ordinary classes to the loss kernel (masking is the trainer's business)
+    z = r16(h) @ r16(w).T + b.double()
+    lse_ref = torch.logsumexp(z, 1)
+    logp = z - lse_ref[:, None]
+    loss_ref = -(1 - eps) * logp[torch.arange(rows), y] - eps * logp.mean(1)
+    gs = 1.0 / rows
+    dz_ref = torch.exp(logp) - eps / V
+    dz_ref[torch.arange(rows), y] -= 1 - eps
+    dz_ref *= gs
+    hs, ws_, bs, ys = h.to(DEV), w.to(DEV), b.to(DEV), y.to(DEV)
+    with ops.compute_dtype("bf16s"):
+        part = torch.empty((rows, ops.ce_tiles(rows, V, K), 4), device=DEV)
+        logits = ops.linear_fwd(hs, ws_, bs, ce_partials=part)
+        lse, loss = ops.ce_finalize(part, logits, ys, eps)
+        d16 = ops.ce_dlogits_bf16(logits, lse, ys, eps, gs)
+        assert d16.dtype == torch.bfloat16 and tuple(d16.shape) == (rows, V)
+        db = torch.empty(V, device=DEV)
+        dw = ops.linear_wgrad(d16, hs, db=db)
+        dh = ops.linear_dgrad(d16, ws_)
+    assert relerr(logits, z) < 2e-5 and relerr(lse, lse_ref) < 1e-5 and relerr(loss, loss_ref) < 1e-5
+    # the bf16 copy is the RNE rounding of the fp32 gradient: 2^-9 relative per element (2^-8 allowed), plus the fp32
+    # exp / cancellation noise of elements where p ~ eps / V (absolute, relative to the gradient scale)
+    assert bool(((d16.double().cpu() - dz_ref).abs() <= 2 ** -8 * dz_ref.abs() + 1e-5 * gs).all())
+    d16d = d16.double().cpu()
+    assert relerr(dw, d16d.T @ r16(h)) < 2e-5 and relerr(db, d16d.sum(0)) < 2e-5
+    assert relerr(dh, d16d @ r16(w)) < 2e-5
+    ldd = d16.stride(0)
+    assert torch.all(torch.as_strided(d16, (rows, ldd), (ldd, 1))[:, V:] == 0)
+
+
+def test_operand_contract_errors_are_reported():
+    ops = _ops()
+    from imagecaption_amd._capi import CapdecError
+    a = torch.randn(16, 12, device=DEV)
+    with ops.compute_dtype("bf16s"):
+        bad = a.to(torch.bfloat16)  # row stride 12: not a multiple of 8
+        with pytest.raises(CapdecError, match="multiple of 8"):
+            ops.gemm(bad, ops.cast_bf16(a), 0, 1)
+        with pytest.raises(CapdecError, match="ce_dlogits_bf16"):
+            ops.gemm(a, a, 0, 1, ce=(torch.zeros(16, device=DEV), torch.zeros(16, dtype=torch.int64, device=DEV), 0.1, 1.0))
+
+
+def test_step_memo_reuses_copies_and_is_off_by_default():
+    ops = _ops()
+    a, b = torch.randn(64, 40, device=DEV), torch.randn(48, 40, device=DEV)
+    assert ops.BF16_MEMO is None
+    with ops.compute_dtype("bf16s"):
+        first = ops.gemm(a, b, 0, 1)
+        b.mul_(2.0)  # without a memo every product sees the current values
+        assert torch.equal(ops.gemm(a, b, 0, 1), 2 * first)
+        ops.BF16_MEMO = {}
+        try:
+            ops.gemm(a, b, 0, 1)
+            assert len(ops.BF16_MEMO) == 2
+            ops.gemm(a, b, 0, 1)
+            assert len(ops.BF16_MEMO) == 2
+        finally:
+            ops.BF16_MEMO = None

@@ -168,3 +168,22 @@ def test_device_prefetcher_yields_the_loader_batches_in_order_and_feeds_the_trai
     assert la == lb                                               # bitwise: same kernels, same data
     with pytest.raises(ValueError):
         DevicePrefetcher(batches, "cpu")
+
+
+def test_out_of_range_token_ids_are_counted_and_reported():
+    """The kernels clamp ids outside [0, V) (no out-of-bounds access) but count them; ops.check_ids raises like the
+    reference's nn.Embedding would (a checkpoint paired with another vocabulary must not train silently)."""
+    from imagecaption_amd import ops
+    E = torch.randn(10, 8, device="cuda")
+    pe = torch.zeros(4, 8, device="cuda")
+    try:
+        ops.check_ids()
+    except IndexError:
+        pass  # whatever earlier tests left behind
+    ops.embed_fwd(torch.tensor([[1, 2, 9]], device="cuda"), E, pe)
+    ops.check_ids()  # all in range: silent
+    out = ops.embed_fwd(torch.tensor([[1, 10, -3]], device="cuda"), E, pe)
+    assert torch.equal(out[0, 1], E[9]) and torch.equal(out[0, 2], E[0])  # clamped, not out of bounds
+    with pytest.raises(IndexError, match="2 token id"):
+        ops.check_ids()
+    ops.check_ids()  # the count was reset

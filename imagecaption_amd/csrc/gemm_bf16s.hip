@@ -210,23 +210,22 @@ void gemm_bf16s_kernel(GemmParams p) {
         }
 }
 
-// Plan: 128 x 128 tiles once they give every CU about one and a half workgroups, else 64 x 64; K slices (combined
-// in the launch) until the grid reaches ~768 workgroups while a slice keeps >= 512 (128-tile) / 256 (64-tile) of K.
+// Plan.  128 x 128 tiles (the LDS-DMA kernel where the operands allow it) unless a dimension is too short to fill
+// them, then 64 x 64; K slices (combined in the launch) until the grid reaches ~512 workgroups while a slice keeps
+// >= 512 of K (measured on the C3 shapes: profiles/r02_gemm_bf16s_sweep.txt).  The k-tile field of a plan selects the
+// 128 x 128 kernel: default = LDS-DMA with one image pair, 32 = LDS-DMA with two image pairs, 16 = register-staged.
 GemmPlan plan_gemm_bf16s(int M, int N, int K, const GemmForce& force) {
     if (force.bm) {
         const int split = force.split > 0 ? force.split : 1;
         const int ks = cdiv(cdiv(K, split), SBK) * SBK;
-        if (force.bm == 256) return GemmPlan{256, 128, SBK, cdiv(K, ks), ks};
+        if (force.bm == 256) return GemmPlan{256, force.bn == 256 ? 256 : 128, SBK, cdiv(K, ks), ks};
         const int bm = force.bm == 128 && force.bn == 128 ? 128 : 64;
-        return GemmPlan{bm, bm, SBK, cdiv(K, ks), ks};
+        return GemmPlan{bm, bm, force.bk ? force.bk : SBK, cdiv(K, ks), ks};
     }
-    const long t128 = (long)cdiv(M, 128) * cdiv(N, 128), t64 = (long)cdiv(M, 64) * cdiv(N, 64);
-    int bm = t128 >= 384 ? 128 : 64, split = 1;
-    if (bm == 128) {
-        while (t128 * split < 768 && K / (split * 2) >= 512 && split < 32) split *= 2;
-    } else {
-        while (t64 * split < 768 && K / (split * 2) >= 256 && split < 32) split *= 2;
-    }
+    const int bm = (M >= 96 && N >= 96) ? 128 : 64;
+    const long tiles = (long)cdiv(M, bm) * cdiv(N, bm);
+    int split = 1;
+    while (tiles * split < 512 && K / (split * 2) >= (bm == 128 ? 512 : 256) && split < 32) split *= 2;
     const int ks = cdiv(cdiv(K, split), SBK) * SBK;
     return GemmPlan{bm, bm, SBK, cdiv(K, ks), ks};
 }
@@ -239,9 +238,13 @@ static void launch_layout(const GemmParams& p, bool AKC, bool BKC, dim3 grid, hi
     else hipLaunchKernelGGL((gemm_bf16s_kernel<BM, BN, false, false>), grid, dim3(256), 0, st, p);
 }
 
+void launch_gemm_bf16s_dma(const GemmParams& p, bool AKC, bool BKC, int bm, int nbuf, dim3 grid, hipStream_t st);
+
 void launch_gemm_bf16s(const GemmParams& p, const GemmPlan& pl, bool AKC, bool BKC, hipStream_t st) {
     dim3 grid(cdiv(p.M, pl.bm) * p.tiles_n, 1, pl.split);
-    if (pl.bm == 256) launch_layout<256, 128>(p, AKC, BKC, grid, st);
+    if (pl.bm == pl.bn && pl.bm >= 128 && pl.bk != 16 && gemm_bf16s_dma_ok(p, AKC, BKC))
+        launch_gemm_bf16s_dma(p, AKC, BKC, pl.bm, pl.bk == 32 ? 2 : 1, grid, st);
+    else if (pl.bm == 256) launch_layout<256, 128>(p, AKC, BKC, grid, st);
     else if (pl.bm == 128) launch_layout<128, 128>(p, AKC, BKC, grid, st);
     else launch_layout<64, 64>(p, AKC, BKC, grid, st);
 }

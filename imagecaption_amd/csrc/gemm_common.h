@@ -45,14 +45,14 @@ constexpr size_t GEMM_COUNTER_BYTES = GEMM_SPLITK_MAX_TILES * 4;  // 16 KiB
 // allocation).  `lds_flag`: one int of the kernel's own (now idle) LDS array.
 typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
 
-template <int TM, int TN>
+template <int TM, int TN, int NT = 256>
 __device__ __forceinline__ bool splitk_combine(const GemmParams& p, f32x16 (&acc)[TM][TN], float& csum, bool do_colsum,
                                                int tile_id, int m0, int bm, int tid, int* lds_flag) {
     const int S = gridDim.z, z = blockIdx.z;
-    constexpr int PER = TM * TN * 4;  // float4 per thread per slab
-    float4* slab0 = reinterpret_cast<float4*>(p.ws) + (size_t)tile_id * S * (PER * 256);
-    float4* mine = slab0 + (size_t)z * (PER * 256);
-    const auto rsrc = __builtin_amdgcn_make_buffer_rsrc(mine, 0, PER * 256 * 16, 0x00020000);
+    constexpr int PER = TM * TN * 4;  // float4 per thread per slab (NT threads per workgroup)
+    float4* slab0 = reinterpret_cast<float4*>(p.ws) + (size_t)tile_id * S * (PER * NT);
+    float4* mine = slab0 + (size_t)z * (PER * NT);
+    const auto rsrc = __builtin_amdgcn_make_buffer_rsrc(mine, 0, PER * NT * 16, 0x00020000);
 #pragma unroll
     for (int i = 0; i < TM; ++i)
 #pragma unroll
@@ -64,7 +64,7 @@ __device__ __forceinline__ bool splitk_combine(const GemmParams& p, f32x16 (&acc
                 v.y = __float_as_uint(acc[i][j][4 * q + 1]);
                 v.z = __float_as_uint(acc[i][j][4 * q + 2]);
                 v.w = __float_as_uint(acc[i][j][4 * q + 3]);
-                __builtin_amdgcn_raw_buffer_store_b128(v, rsrc, (((i * TN + j) * 4 + q) * 256 + tid) * 16, 0, 16 /* sc1 */);
+                __builtin_amdgcn_raw_buffer_store_b128(v, rsrc, (((i * TN + j) * 4 + q) * NT + tid) * 16, 0, 16 /* sc1 */);
             }
     if (do_colsum && tid < bm)
         __hip_atomic_store(&p.ws_colsum[(size_t)z * p.m_pad + m0 + tid], csum, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
@@ -91,14 +91,14 @@ __device__ __forceinline__ bool splitk_combine(const GemmParams& p, f32x16 (&acc
     constexpr int UNR = PER >= 8 ? 1 : 8 / PER;
 #pragma unroll UNR
     for (int s = 0; s < S; ++s) {
-        const float4* sl = slab0 + (size_t)s * (PER * 256);
+        const float4* sl = slab0 + (size_t)s * (PER * NT);
 #pragma unroll
         for (int i = 0; i < TM; ++i)
 #pragma unroll
             for (int j = 0; j < TN; ++j)
 #pragma unroll
                 for (int q = 0; q < 4; ++q) {
-                    const float4 v = sl[((i * TN + j) * 4 + q) * 256 + tid];
+                    const float4 v = sl[((i * TN + j) * 4 + q) * NT + tid];
                     acc[i][j][4 * q] += v.x; acc[i][j][4 * q + 1] += v.y;
                     acc[i][j][4 * q + 2] += v.z; acc[i][j][4 * q + 3] += v.w;
                 }
@@ -145,20 +145,22 @@ __device__ __forceinline__ int ce_target(const GemmParams& p, int row, int V) {
 // columns: (max, sum exp(z - max), sum z).  32 rows at a time go through LDS as [row][BN + 1] (written by the two
 // waves that own them in the accumulator layout), then 8 threads per row reduce BN / 8 columns each.  `lds`: the
 // kernel's own (idle) LDS array, >= 32 * (BN + 1) floats.
-template <int TM, int TN, int BM, int BN>
+template <int TM, int TN, int BM, int BN, int WN = 2, int NT = 256>
 __device__ __forceinline__ void ce_tile_partials(const GemmParams& p, const f32x16 (&acc)[TM][TN], float* lds, int m0,
                                                  int n0, int tile_n, int tid) {
-    constexpr int LDR = BN + 1, CPT = BN / 8;
+    // WN waves side by side along N (each 32 * TN columns), NT / 64 / WN wave rows (each 32 * TM rows); NT / 32
+    // threads reduce one row
+    constexpr int LDR = BN + 1, TPR = NT / 32, CPT = BN / TPR, WM = NT / 64 / WN;
     const int lane = tid & 63, wave = tid >> 6, l31 = lane & 31, half = lane >> 5;
-    const int wr = wave >> 1, wc = wave & 1;
+    const int wr = wave / WN, wc = wave % WN;
 #pragma unroll
-    for (int c = 0; c < 2 * TM; ++c) {
+    for (int c = 0; c < WM * TM; ++c) {
         const int cw = c / TM, ci = c % TM;
         __syncthreads();
         if (wr == cw) {
 #pragma unroll
             for (int j = 0; j < TN; ++j) {
-                const int col = wc * (BN / 2) + j * 32 + l31;
+                const int col = wc * (32 * TN) + j * 32 + l31;
                 const int n = n0 + col;
                 const float b = (p.bias && n < p.N) ? p.bias[n] : 0.f;
 #pragma unroll
@@ -166,7 +168,7 @@ __device__ __forceinline__ void ce_tile_partials(const GemmParams& p, const f32x
             }
         }
         __syncthreads();
-        const int row = tid >> 3, part = tid & 7;
+        const int row = tid / TPR, part = tid % TPR;
         float v[CPT];
         float mx = -INFINITY, sz = 0.f;
 #pragma unroll
@@ -177,16 +179,17 @@ __device__ __forceinline__ void ce_tile_partials(const GemmParams& p, const f32x
             mx = fmaxf(mx, v[k]);
             sz += ok ? v[k] : 0.f;
         }
-        mx = fmaxf(mx, __shfl_xor(mx, 1, 64));
-        mx = fmaxf(mx, __shfl_xor(mx, 2, 64));
-        mx = fmaxf(mx, __shfl_xor(mx, 4, 64));
+#pragma unroll
+        for (int o = 1; o < TPR; o <<= 1) mx = fmaxf(mx, __shfl_xor(mx, o, 64));
         float se = 0.f;
 #pragma unroll
         for (int k = 0; k < CPT; ++k) se += __expf(v[k] - mx);  // excluded columns: exp(-inf) = 0 (mx is finite: col 0 is in)
-        se += __shfl_xor(se, 1, 64); sz += __shfl_xor(sz, 1, 64);
-        se += __shfl_xor(se, 2, 64); sz += __shfl_xor(sz, 2, 64);
-        se += __shfl_xor(se, 4, 64); sz += __shfl_xor(sz, 4, 64);
-        const int m = m0 + cw * (BM / 2) + ci * 32 + row;
+#pragma unroll
+        for (int o = 1; o < TPR; o <<= 1) {
+            se += __shfl_xor(se, o, 64);
+            sz += __shfl_xor(sz, o, 64);
+        }
+        const int m = m0 + cw * (BM / WM) + ci * 32 + row;
         if (part == 0 && m < p.M) p.ce_part[(size_t)m * p.tiles_n + tile_n] = make_float4(mx, se, sz, 0.f);
     }
 }
@@ -214,5 +217,6 @@ GemmPlan plan_gemm_f32x3(int M, int N, int K, const GemmForce& force);
 int launch_gemm_f32x3(const GemmParams& p, const GemmPlan& pl, bool AK, bool BKM, bool vec, hipStream_t st);
 GemmPlan plan_gemm_bf16s(int M, int N, int K, const GemmForce& force);
 void launch_gemm_bf16s(const GemmParams& p, const GemmPlan& pl, bool AKC, bool BKC, hipStream_t st);  // A, B: bf16
+bool gemm_bf16s_dma_ok(const GemmParams& p, bool AKC, bool BKC);  // operands fit the LDS-DMA kernels (gemm_bf16s_dma.hip)
 
 }  // namespace capdec

@@ -374,7 +374,7 @@ static void launch_cfg(const GemmParams& p, bool AK, bool BKM, bool vec, dim3 gr
 using namespace capdec;
 
 extern "C" int capdec_gemm_tune(int bm, int bn, int split, int bk) {
-    const bool ok = ((bm == 0) || (((bm == 64 || bm == 128) && (bn == 64 || bn == 128) || (bm == 256 && bn == 128)) &&
+    const bool ok = ((bm == 0) || (((bm == 64 || bm == 128) && (bn == 64 || bn == 128) || (bm == 256 && (bn == 128 || bn == 256))) &&
                                    split >= 1 && split <= 64)) &&
                     (bk == 0 || bk == 16 || bk == 32);
     CAPDEC_REQUIRE(ok, "capdec_gemm_tune: unsupported tile %dx%d split %d bk %d", bm, bn, split, bk);
@@ -393,7 +393,7 @@ static GemmPlan clamp_plan(GemmPlan pl, int M, int N, int K) {
 
 static GemmPlan plan_for(int ta, int tb, int M, int N, int K, int dtype) {
     GemmForce f = resolve_force(ta, tb, M, N, K, dtype);
-    if (f.bm == 256 && dtype != CAPDEC_BF16S) f.bm = 128;  // the 256 x 128 tile exists for bf16 storage only
+    if (f.bm == 256 && dtype != CAPDEC_BF16S) f.bm = f.bn = 128;  // the 256-row tiles exist for bf16 storage only
     return dtype == CAPDEC_BF16 ? plan_gemm_bf16(M, N, K, f) : dtype == CAPDEC_F32X3 ? plan_gemm_f32x3(M, N, K, f)
            : dtype == CAPDEC_BF16S ? plan_gemm_bf16s(M, N, K, f) : plan_gemm(M, N, K, f);
 }
@@ -405,7 +405,7 @@ extern "C" int capdec_gemm_ce_tiles(int M, int N, int K, int dtype) {
 
 extern "C" int capdec_gemm_plan_set(int transA, int transB, int M, int N, int K, int dtype, int bm, int bn, int split,
                                     int bk) {
-    const bool ok = bm == 0 || (((bm == 64 || bm == 128) && (bn == 64 || bn == 128) || (bm == 256 && bn == 128 && dtype == CAPDEC_BF16S)) &&
+    const bool ok = bm == 0 || (((bm == 64 || bm == 128) && (bn == 64 || bn == 128) || (bm == 256 && (bn == 128 || bn == 256) && dtype == CAPDEC_BF16S)) &&
                                 split >= 1 && split <= 64 && (bk == 0 || bk == 16 || bk == 32));
     CAPDEC_REQUIRE(ok && M > 0 && N > 0 && K > 0, "capdec_gemm_plan_set: unsupported plan %dx%d split %d bk %d", bm, bn, split, bk);
     std::lock_guard<std::mutex> lock(g_plan_mu);
@@ -482,6 +482,13 @@ extern "C" int capdec_gemm(int transA, int transB, int M, int N, int K, const vo
         CAPDEC_REQUIRE(ep->drop_p >= 0.f && ep->drop_p < 1.f, "capdec_gemm: drop_p out of range");
     }
     GemmPlan pl = clamp_plan(plan_for(transA, transB, M, N, K, dtype), M, N, K);
+    if (dtype == CAPDEC_BF16S && pl.bn == 256 && !gemm_bf16s_dma_ok(p, !transA, transB != 0)) {
+        // the 256 x 256 block exists only in the LDS-DMA form; these operands need the register-staged 256 x 128 one
+        CAPDEC_REQUIRE(!p.ce_part, "capdec_gemm: ce_partials was sized by capdec_gemm_ce_tiles for a 256-column plan, which "
+                                   "needs bf16 operands whose pitch covers K rounded up to 64 (zero padded)");
+        pl.bn = 128;
+        pl = clamp_plan(pl, M, N, K);
+    }
     if (p.ce_part) {  // a row's partials come from whole column tiles: no K split (the vocabulary product has none)
         pl.split = 1;
         pl.ksplit = K;

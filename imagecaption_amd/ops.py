@@ -33,10 +33,11 @@ BF16_MEMO = None
 
 
 def _bf16_pitch(cols):
-    """Row stride (elements) of a bf16 copy: a multiple of 8 covering the row; a pitch that is a multiple of 1 KiB
+    """Row stride (elements) of a bf16 copy: the row rounded up to 64 -- the zero padding behind the row is what lets
+    the LDS-DMA GEMM kernel (which cannot mask a load) run the reduction tail; a pitch that is a multiple of 1 KiB
     would put every row of a GEMM tile on the same few L2 / HBM channels, so such pitches get one more 128-byte line."""
-    ldd = (cols + 7) // 8 * 8
-    if os.environ.get("CAPDEC_BF16_NOPAD") is None and ldd % 512 == 0:
+    ldd = (cols + 63) // 64 * 64
+    if ldd % 512 == 0:
         ldd += 64
     return ldd
 
@@ -234,7 +235,7 @@ _TUNED = {}         # the same key -> (bm, bn, split, bk) already pinned in this
 
 def _plan_candidates(dtype, M, N, K):
     tiles_by = {F32: [(128, 128), (128, 64), (64, 128), (64, 64)], _capi.BF16: [(128, 128), (64, 64)],
-                _capi.F32X3: [(128, 128), (128, 64), (64, 64)], _capi.BF16S: [(256, 128), (128, 128), (64, 64)]}[dtype]
+                _capi.F32X3: [(128, 128), (128, 64), (64, 64)], _capi.BF16S: [(256, 256), (256, 128), (128, 128), (64, 64)]}[dtype]
     bks = (16, 32) if dtype == F32 else (0,)
     for bm, bn in tiles_by:
         tiles = -(-M // bm) * -(-N // bn)
@@ -243,6 +244,8 @@ def _plan_candidates(dtype, M, N, K):
                 continue  # a chip-filling grid gains nothing from K slices; the ticket array holds 4096 tiles
             for bk in bks:
                 yield bm, bn, split, bk
+            if dtype == _capi.BF16S and bm == 128:  # the LDS-DMA kernel with two image pairs instead of one
+                yield bm, bn, split, 32
 
 
 def tune_gemm_plans(signatures, reps=4, min_gain=0.03, verbose=False):

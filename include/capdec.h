@@ -94,7 +94,7 @@ typedef struct capdec_epilogue {
 #define CAPDEC_GEMM_TICKET_BYTES 16384
 size_t capdec_gemm_workspace_bytes(int M, int N, int K);
 /* Tuning hook (process-global, not thread-safe): force block tile bm x bn in {64,128}^2 (CAPDEC_BF16S: 64 x 64,
- * 128 x 128 or 256 x 128; other compute types run a forced 256 x 128 as 128 x 128) and a split-K
+ * 128 x 128, 256 x 128 or 256 x 256; other compute types run a forced 256-row tile as 128 x 128) and a split-K
  * factor (and k-tile bk in {0 = default, 16, 32}) for every following capdec_gemm call; bm = 0
  * restores the built-in cost model. */
 int capdec_gemm_tune(int bm, int bn, int split, int bk);

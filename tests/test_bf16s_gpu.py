@@ -63,15 +63,19 @@ def test_gemm_reads_bf16_operands_in_either_orientation(M, N, K, ta, tb):
     with ops.compute_dtype("bf16s"):
         out = ops.gemm(a.to(DEV), b.to(DEV), ta, tb)                                  # fp32 operands: cast inside
         out2 = ops.gemm(ops.cast_bf16(a.to(DEV)), ops.cast_bf16(b.to(DEV)), ta, tb)   # bf16 operands as given
-        try:  # the large tile (one LDS image, 128 x 64 per wave) on the same ragged shapes
-            l.capdec_gemm_tune(256, 128, 1, 0)
-            out3 = ops.gemm(a.to(DEV), b.to(DEV), ta, tb)
+        others = []
+        try:  # every kernel family on the same ragged shapes: register-staged 64 / 128 (k-tile 16 = no DMA) / 256 x 128,
+            # LDS-DMA 128 x 128 with one or two (k-tile 32) image pairs, LDS-DMA 256 x 256
+            for bm, bn, bk in ((64, 64, 0), (128, 128, 16), (256, 128, 0), (128, 128, 32), (128, 128, 0), (256, 256, 0)):
+                l.capdec_gemm_tune(bm, bn, 1, bk)
+                others.append(ops.gemm(a.to(DEV), b.to(DEV), ta, tb))
         finally:
             l.capdec_gemm_tune(0, 0, 0, 0)
     assert out.dtype == torch.float32
     assert relerr(out, ref) < 2e-6 * math.sqrt(K)
     assert torch.equal(out, out2)
-    assert relerr(out3, ref) < 2e-6 * math.sqrt(K)
+    for i, o in enumerate(others):
+        assert relerr(o, ref) < 2e-6 * math.sqrt(K), i
 
 
 def test_gemm_asymmetric_identity_all_layouts():
@@ -106,8 +110,10 @@ def test_forced_plans_splitk_epilogue_and_bias_gradient():
                 want_tn = r16(dy).T @ r16(a2)
                 want_cs = r16(dy).sum(0)
                 xs, ws_, bs, rs, dys, a2s = (t.to(DEV) for t in (x, w, b, r, dy, a2))
-                for bm, split in ((64, 1), (64, 4), (128, 2), (128, 1), (64, 16), (128, 8), (256, 1), (256, 4)):
-                    l.capdec_gemm_tune(bm, min(bm, 128), split, 0)
+                for bm, bn, split, bk in ((64, 64, 1, 0), (64, 64, 4, 0), (128, 128, 2, 0), (128, 128, 1, 32), (64, 64, 16, 0),
+                                          (128, 128, 8, 32), (128, 128, 3, 16), (256, 128, 1, 0), (256, 128, 4, 0),
+                                          (256, 256, 1, 0), (256, 256, 4, 0)):
+                    l.capdec_gemm_tune(bm, bn, split, bk)
                     ops._WS_NEED.clear()
                     outs = []
                     for _ in range(2):
@@ -115,10 +121,10 @@ def test_forced_plans_splitk_epilogue_and_bias_gradient():
                         cs = torch.empty(M, device=DEV)
                         o2 = ops.gemm(dys, a2s, True, False, colsum=cs)
                         outs.append((o, o2, cs))
-                    assert relerr(outs[0][0], want) < 2e-5, (M, N, K, bm, split)
-                    assert relerr(outs[0][1], want_tn) < 2e-5 and relerr(outs[0][2], want_cs) < 2e-5, (M, N, K, bm, split)
+                    assert relerr(outs[0][0], want) < 2e-5, (M, N, K, bm, bn, split, bk)
+                    assert relerr(outs[0][1], want_tn) < 2e-5 and relerr(outs[0][2], want_cs) < 2e-5, (M, N, K, bm, bn, split, bk)
                     for p, q in zip(outs[0], outs[1]):
-                        assert torch.equal(p, q), (M, N, K, bm, split)
+                        assert torch.equal(p, q), (M, N, K, bm, bn, split, bk)
     finally:
         l.capdec_gemm_tune(0, 0, 0, 0)
         ops._WS_NEED.clear()

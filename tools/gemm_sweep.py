@@ -38,7 +38,7 @@ l = _capi.lib()
 DT = os.environ.get("SWEEP_DTYPE", "fp32")
 ops.COMPUTE_DTYPE = {"fp32": _capi.F32, "bf16": _capi.BF16, "f32x3": _capi.F32X3, "bf16s": _capi.BF16S}[DT]
 CANDS = {"fp32": [(128, 128), (128, 64), (64, 128), (64, 64)], "bf16": [(128, 128), (64, 64)],
-         "f32x3": [(128, 128), (128, 64), (64, 64)], "bf16s": [(256, 128), (128, 128), (64, 64)]}[DT]
+         "f32x3": [(128, 128), (128, 64), (64, 64)], "bf16s": [(256, 256), (256, 128), (128, 128), (64, 64)]}[DT]
 SPLITS = [1, 2, 3, 4, 5, 6, 8, 10, 12, 16] if not os.environ.get("SWEEP_FEW") else [1, 2, 4, 8]
 BKS = [16, 32] if DT == "fp32" else [0]
 for ta, tb, M, N, K in SHAPES:
@@ -52,7 +52,8 @@ for ta, tb, M, N, K in SHAPES:
     ops._WS_NEED.clear()
     t = timeit(lambda: ops.gemm(a, b, ta, tb, out=out))
     res.append(("auto", t))
-    for (bm, bn), sp, bk in itertools.product(CANDS, SPLITS, BKS):
+    for (bm, bn), sp, bk in itertools.product(CANDS, SPLITS, BKS if DT != "bf16s" else [0, 32]):
+        if DT == "bf16s" and bk == 32 and bm != 128: continue  # 32 = the two-image form of the LDS-DMA kernel
         if sp > 1 and K // sp < 128: continue
         if sp > 1 and M * N * sp * 4 > (1 << 30): continue
         l.capdec_gemm_tune(bm, bn, sp, bk)

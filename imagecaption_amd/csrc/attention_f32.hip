@@ -26,6 +26,7 @@ struct AttnParams {
     float* out; float* lse; float* delta; float* dq; float* dk; float* dv;
     int ldq, ldk, ldv, ldo, lddo, lddq, lddk, lddv;
     int B, H, Tq, Tk, causal;
+    int dkv_bf16;  // dk / dv point to bf16 matrices (lddk / lddv in bf16 elements): capdec_attn_bwd_dkv16
     float scale;
     Dropout drop;
 };
@@ -494,6 +495,22 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2))) void at
         mma_acc_lds<DH>(dvacc, pd, dOs, l31, half);
         mma_acc_lds<DH>(dkacc, ds, Qs, l31, half);
     }
+    if (p.dkv_bf16) {  // the gradients only feed matrix products that read bf16 copies: write those directly
+        __bf16* dkg = reinterpret_cast<__bf16*>(p.dk) + (size_t)b * p.Tk * p.lddk + h * DH;
+        __bf16* dvg = reinterpret_cast<__bf16*>(p.dv) + (size_t)b * p.Tk * p.lddv + h * DH;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int kk = k0 + row_of(r, half);
+            if (kk < p.Tk) {
+#pragma unroll
+                for (int dt = 0; dt < DH / 32; ++dt) {
+                    dkg[(size_t)kk * p.lddk + dt * 32 + l31] = (__bf16)dkacc[dt][r];
+                    dvg[(size_t)kk * p.lddv + dt * 32 + l31] = (__bf16)dvacc[dt][r];
+                }
+            }
+        }
+        return;
+    }
     float* dkg = p.dk + (size_t)b * p.Tk * p.lddk + h * DH;
     float* dvg = p.dv + (size_t)b * p.Tk * p.lddv + h * DH;
 #pragma unroll
@@ -612,17 +629,20 @@ extern "C" int capdec_attn_fwd(const void* q, int ldq, const void* k, int ldk, c
     return check_launch("capdec_attn_fwd");
 }
 
-extern "C" int capdec_attn_bwd(const void* q, int ldq, const void* k, int ldk, const void* v, int ldv, const void* o,
-                               int ldo, const void* dout, int lddo, const void* lse, void* delta, void* dq, int lddq,
-                               void* dk, int lddk, void* dv, int lddv, int B, int H, int Tq, int Tk, int dh, int causal,
-                               float scale, float drop_p, uint64_t drop_seed, capdec_stream_t stream) {
+static int attn_bwd_impl(const void* q, int ldq, const void* k, int ldk, const void* v, int ldv, const void* o,
+                         int ldo, const void* dout, int lddo, const void* lse, void* delta, void* dq, int lddq,
+                         void* dk, int lddk, void* dv, int lddv, int B, int H, int Tq, int Tk, int dh, int causal,
+                         float scale, float drop_p, uint64_t drop_seed, capdec_stream_t stream, int dkv_bf16) {
     if (int rc = check_common("capdec_attn_bwd", B, H, Tq, Tk, dh)) return rc;
     CAPDEC_REQUIRE(ok_mat(q, ldq, H, dh) && ok_mat(k, ldk, H, dh) && ok_mat(v, ldv, H, dh) && ok_mat(o, ldo, H, dh) &&
                        ok_mat(dout, lddo, H, dh) && (ok_mat(dq, lddq, H, dh) || (Tk == 1 && !dq)) &&
                        ok_mat(dk, lddk, H, dh) && ok_mat(dv, lddv, H, dh) && (Tk == 1 || (lse && delta)),
                    "capdec_attn_bwd: operands must be non-null, 16-byte aligned, ld %% 4 == 0, ld >= H*dh");
+    CAPDEC_REQUIRE(!dkv_bf16 || (Tk > 1 && lddk % 8 == 0 && lddv % 8 == 0),
+                   "capdec_attn_bwd_dkv16: needs Tk > 1 and lddk / lddv (bf16 elements) that are multiples of 8");
     AttnParams p;
     memset(&p, 0, sizeof(p));
+    p.dkv_bf16 = dkv_bf16;
     p.q = (const float*)q; p.k = (const float*)k; p.v = (const float*)v; p.o = (const float*)o;
     p.dout = (const float*)dout; p.lse = (float*)lse; p.delta = (float*)delta;
     p.dq = (float*)dq; p.dk = (float*)dk; p.dv = (float*)dv;
@@ -646,4 +666,20 @@ extern "C" int capdec_attn_bwd(const void* q, int ldq, const void* k, int ldk, c
         hipLaunchKernelGGL(attn_bwd_dkv_kernel<128>, gk, dim3(64), 0, st, p);
     }
     return check_launch("capdec_attn_bwd");
+}
+
+extern "C" int capdec_attn_bwd(const void* q, int ldq, const void* k, int ldk, const void* v, int ldv, const void* o,
+                               int ldo, const void* dout, int lddo, const void* lse, void* delta, void* dq, int lddq,
+                               void* dk, int lddk, void* dv, int lddv, int B, int H, int Tq, int Tk, int dh, int causal,
+                               float scale, float drop_p, uint64_t drop_seed, capdec_stream_t stream) {
+    return attn_bwd_impl(q, ldq, k, ldk, v, ldv, o, ldo, dout, lddo, lse, delta, dq, lddq, dk, lddk, dv, lddv, B, H, Tq, Tk,
+                         dh, causal, scale, drop_p, drop_seed, stream, 0);
+}
+
+extern "C" int capdec_attn_bwd_dkv16(const void* q, int ldq, const void* k, int ldk, const void* v, int ldv, const void* o,
+                                     int ldo, const void* dout, int lddo, const void* lse, void* delta, void* dq, int lddq,
+                                     void* dk16, int lddk, void* dv16, int lddv, int B, int H, int Tq, int Tk, int dh,
+                                     int causal, float scale, float drop_p, uint64_t drop_seed, capdec_stream_t stream) {
+    return attn_bwd_impl(q, ldq, k, ldk, v, ldv, o, ldo, dout, lddo, lse, delta, dq, lddq, dk16, lddk, dv16, lddv, B, H, Tq,
+                         Tk, dh, causal, scale, drop_p, drop_seed, stream, 1);
 }

@@ -219,7 +219,17 @@ def stack_bwd(layers, grads, norm_w, norm_b, g_norm_w, g_norm_b, sv, dy, mem, B,
     # involved, so the bucket order of the data-parallel reducer is untouched)
     w_all = sv.get("w_kv_all")
     d = dy.shape[1]
-    dkv_all = torch.empty((mem.shape[0], w_all.shape[0]), dtype=torch.float32, device=dy.device) if w_all is not None else None
+    dkv_all = None
+    if w_all is not None:
+        if ops.COMPUTE_DTYPE == ops.BF16S and S > 1:
+            # the only readers of dK | dV are bf16-storage products: the attention backward writes their operand
+            # directly (no fp32 block, no cast pass); the padding columns of the pitch must read as zeros
+            pitch = ops._bf16_pitch(w_all.shape[0])
+            buf = torch.empty((mem.shape[0], pitch), dtype=torch.bfloat16, device=dy.device)
+            buf[:, w_all.shape[0]:].zero_()
+            dkv_all = buf[:, :w_all.shape[0]]
+        else:
+            dkv_all = torch.empty((mem.shape[0], w_all.shape[0]), dtype=torch.float32, device=dy.device)
     for l in range(len(layers) - 1, -1, -1):
         dx, dmem = layer_bwd(layers[l], grads[l], sv["layers"][l], dx, mem, dmem, B, T, S, H, causal, dp, l,
                              dkv=None if dkv_all is None else dkv_all[:, l * 2 * d:(l + 1) * 2 * d])

@@ -24,6 +24,7 @@ __all__ = ["compute_dtype", "gemm", "linear_fwd", "linear_dgrad", "linear_wgrad"
 # BF16S: the same arithmetic on bf16 COPIES of the operands (capdec_cast_bf16): the products read half the bytes and
 # convert nothing; results, epilogues, norms, attention, loss and optimizer state stay fp32.
 COMPUTE_DTYPE = F32
+BF16S = _capi.BF16S
 
 # bf16 copies made during one training step: (data_ptr, rows, cols, row stride) -> (source, copy).  None = off: every
 # product casts its operands afresh.  Only a caller that knows when tensors change may switch it on (CaptionTrainer:
@@ -546,7 +547,8 @@ def attn_fwd(q, k, v, B, H, Tq, Tk, causal, drop_p=0.0, seed=0, out=None, save_l
 
 
 def attn_bwd(q, k, v, o, do, lse, B, H, Tq, Tk, causal, drop_p=0.0, seed=0, dq=None, dk=None, dv=None, need_dq=True):
-    """``need_dq=False`` is accepted for Tk == 1 only (dq is exactly zero there and is then not written)."""
+    """``need_dq=False`` is accepted for Tk == 1 only (dq is exactly zero there and is then not written).
+    bf16 ``dk`` / ``dv`` (both, Tk > 1): the gradients are written as bf16 matrices (capdec_attn_bwd_dkv16)."""
     D = q.shape[1]
     dh = D // H
     _mat(do, "attn_bwd.do")
@@ -558,9 +560,13 @@ def attn_bwd(q, k, v, o, do, lse, B, H, Tq, Tk, causal, drop_p=0.0, seed=0, dq=N
     dv = torch.empty((B * Tk, D), dtype=torch.float32, device=q.device) if dv is None else dv
     delta = torch.empty((B, H, Tq), dtype=torch.float32, device=q.device)
     # algorithmic bytes: read Q, K, V, O, dO; write dQ, dK, dV
+    kv16 = dk.dtype == torch.bfloat16
+    if kv16 != (dv.dtype == torch.bfloat16):
+        raise _capi.CapdecError("attn_bwd: dk and dv must have the same dtype")
+    fn = lib().capdec_attn_bwd_dkv16 if kv16 else lib().capdec_attn_bwd
     with _Timed(f"attn_bwd_{'causal' if causal else 'cross'}_{Tq}x{Tk}", 10.0 * B * H * Tq * Tk * dh,
-                4.0 * B * D * (4 * Tq + 4 * Tk)):
-        check(lib().capdec_attn_bwd(ptr(q), q.stride(0), ptr(k), k.stride(0), ptr(v), v.stride(0), ptr(o), o.stride(0),
+                4.0 * B * D * (4 * Tq + (3 if kv16 else 4) * Tk)):
+        check(fn(ptr(q), q.stride(0), ptr(k), k.stride(0), ptr(v), v.stride(0), ptr(o), o.stride(0),
                                     ptr(do), do.stride(0), ptr(lse), ptr(delta), ptr(dq), dq.stride(0) if dq is not None else D,
                                     ptr(dk),
                                     dk.stride(0), ptr(dv), dv.stride(0), B, H, Tq, Tk, dh, int(causal),

@@ -210,6 +210,14 @@ int capdec_attn_bwd(const void* q, int ldq, const void* k, int ldk, const void* 
                     const void* dout, int lddo, const void* lse, void* delta, void* dq, int lddq, void* dk, int lddk,
                     void* dv, int lddv, int B, int H, int Tq, int Tk, int dh, int causal, float scale, float drop_p,
                     uint64_t drop_seed, capdec_stream_t stream);
+/* capdec_attn_bwd with dK / dV written as bf16 matrices (lddk / lddv in bf16 elements, multiples of 8; Tk > 1): for
+ * callers whose only consumers of dK / dV are CAPDEC_BF16S products (the cross-attention K/V projection's weight
+ * and input gradients) -- saves the fp32 round trip and the cast pass of the step's largest gradient block.
+ * Same computation as capdec_attn_bwd; the stored values are its fp32 results rounded to nearest even. */
+int capdec_attn_bwd_dkv16(const void* q, int ldq, const void* k, int ldk, const void* v, int ldv, const void* o, int ldo,
+                          const void* dout, int lddo, const void* lse, void* delta, void* dq, int lddq, void* dk16,
+                          int lddk, void* dv16, int lddv, int B, int H, int Tq, int Tk, int dh, int causal, float scale,
+                          float drop_p, uint64_t drop_seed, capdec_stream_t stream);
 
 /* ---- label-smoothed softmax cross-entropy, forward + backward in one pass -------------------------
  * Per row m of logits [M,V] (row stride ldl) with target y = targets[m] (int64):

@@ -197,3 +197,23 @@ def test_step_memo_reuses_copies_and_is_off_by_default():
             assert len(ops.BF16_MEMO) == 2
         finally:
             ops.BF16_MEMO = None
+
+
+@pytest.mark.parametrize("B,H,Tq,Tk,dh,causal", [(2, 8, 20, 196, 128, False), (3, 4, 12, 12, 32, True), (2, 2, 7, 45, 64, False)])
+def test_attention_backward_writes_bf16_key_value_gradients(B, H, Tq, Tk, dh, causal):
+    """capdec_attn_bwd_dkv16: the same dK / dV as the fp32 entry point, rounded to nearest even, in a padded bf16 block
+    (row-strided views, as the batched cross K/V backward uses them); dQ is untouched by the variant."""
+    ops = _ops()
+    g = torch.Generator().manual_seed(B * 100 + Tk)
+    D = H * dh
+    q, do = torch.randn(B * Tq, D, generator=g).to(DEV), torch.randn(B * Tq, D, generator=g).to(DEV)
+    kv = torch.randn(B * Tk, 2 * D, generator=g).to(DEV)
+    k, v = kv[:, :D], kv[:, D:]
+    o, lse = ops.attn_fwd(q, k, v, B, H, Tq, Tk, causal, 0.1, 77)
+    dq, dk, dv = ops.attn_bwd(q, k, v, o, do, lse, B, H, Tq, Tk, causal, 0.1, 77)
+    pitch = ops._bf16_pitch(2 * D)
+    buf = torch.full((B * Tk, pitch), 7.0, dtype=torch.bfloat16, device=DEV)
+    dq2, dk16, dv16 = ops.attn_bwd(q, k, v, o, do, lse, B, H, Tq, Tk, causal, 0.1, 77, dk=buf[:, :D], dv=buf[:, D:2 * D])
+    assert torch.equal(dq, dq2)
+    assert torch.equal(dk16, dk.to(torch.bfloat16)) and torch.equal(dv16, dv.to(torch.bfloat16))
+    assert torch.all(buf[:, 2 * D:] == 7.0)  # nothing outside the two blocks is written

@@ -111,15 +111,73 @@ __device__ __forceinline__ bool splitk_combine(const GemmParams& p, f32x16 (&acc
     return true;
 }
 
-__device__ __forceinline__ float epilogue_apply(const GemmParams& p, float v, int m, int n) {
-    if (p.bias) v += p.bias[n];
-    const size_t o = (size_t)m * p.ldc + n;
-    if (p.pre) p.pre[o] = v;
-    if (p.act == CAPDEC_ACT_GELU) v = gelu_erf(v);
-    else if (p.act == CAPDEC_ACT_GELU_BWD) v *= gelu_erf_grad(p.aux[o]);
-    if (p.drop.on()) v = p.drop.apply(v, (uint32_t)m * (uint32_t)p.N + (uint32_t)n);
-    if (p.addend) v += p.addend[(size_t)m * p.ld_addend + n];
-    return v;
+// The fused epilogue over a wave's accumulators (32 x 32 MFMA layout: lane (l31, half) holds column l31 and rows
+// (r & 3) + 8 (r >> 2) + 4 half of each 32 x 32 block), written so that no load ever waits behind a store: on gfx9
+// loads and stores share one in-order counter, and an element-by-element "load bias / residual, add, store" loop
+// makes every load wait for the previous element's store to be acknowledged (~64 serialized round trips per lane
+// and tile -- the shape this epilogue had before).  Here the bias is read once per column, and the residual /
+// GELU-input values of the NEXT half block (8 elements) are requested before the current half block is stored.
+// Same arithmetic, in the same order, as before: v = acc + bias; pre = v; activation; dropout; + addend.
+template <int TM, int TN>
+__device__ __forceinline__ void epilogue_store(const GemmParams& p, const f32x16 (&acc)[TM][TN], int mbase, int nbase,
+                                               int l31, int half) {
+    float bj[TN];
+#pragma unroll
+    for (int j = 0; j < TN; ++j) {
+        const int n = nbase + j * 32 + l31;
+        bj[j] = (p.bias && n < p.N) ? p.bias[n] : 0.f;
+    }
+    // one staged stream: the residual if there is one, else the GELU input (both at once -- no caller of this
+    // library does that -- reads the GELU input in place, the slow way)
+    const bool has_add = p.addend != nullptr, gbwd = p.act == CAPDEC_ACT_GELU_BWD;
+    const float* stg = has_add ? p.addend : p.aux;
+    const int ld_stg = has_add ? p.ld_addend : p.ldc;
+    const bool staged = has_add || gbwd;
+    float st[2][8];
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int j = 0; j < TN; ++j) {
+            const int n = nbase + j * 32 + l31;
+#pragma unroll
+            for (int h8 = 0; h8 < 2; ++h8) {
+                // request the next half block (8 elements) before this one is stored
+                const bool first = i == 0 && j == 0 && h8 == 0, last = i == TM - 1 && j == TN - 1 && h8 == 1;
+                const int cur = h8, nxt = h8 ^ 1;
+                if (first) {
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) {
+                        const int m = mbase + (e & 3) + 8 * (e >> 2) + 4 * half;
+                        st[0][e] = (staged && m < p.M && n < p.N) ? stg[(size_t)m * ld_stg + n] : 0.f;
+                    }
+                }
+                if (!last) {
+                    const int i2 = h8 ? (j == TN - 1 ? i + 1 : i) : i, j2 = h8 ? (j == TN - 1 ? 0 : j + 1) : j;
+                    const int n2 = nbase + j2 * 32 + l31;
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) {
+                        const int r = nxt * 8 + e;
+                        const int m = mbase + i2 * 32 + (r & 3) + 8 * (r >> 2) + 4 * half;
+                        st[nxt][e] = (staged && m < p.M && n2 < p.N) ? stg[(size_t)m * ld_stg + n2] : 0.f;
+                    }
+                }
+#pragma unroll
+                for (int e = 0; e < 8; ++e) {
+                    const int r = h8 * 8 + e;
+                    const int m = mbase + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * half;
+                    if (m < p.M && n < p.N) {
+                        const size_t o = (size_t)m * p.ldc + n;
+                        float v = acc[i][j][r] + bj[j];
+                        if (p.pre) p.pre[o] = v;
+                        if (p.act == CAPDEC_ACT_GELU) v = gelu_erf(v);
+                        else if (gbwd) v *= gelu_erf_grad(has_add ? p.aux[o] : st[cur][e]);
+                        if (p.drop.on()) v = p.drop.apply(v, (uint32_t)m * (uint32_t)p.N + (uint32_t)n);
+                        if (has_add) v += st[cur][e];
+                        p.C[o] = v;
+                    }
+                }
+            }
+        }
 }
 
 // ---- fused cross-entropy pieces shared by the three GEMM kernels (same accumulator layout) ---------------------

@@ -294,17 +294,7 @@ void gemm_f32_kernel(GemmParams p) {
         return;
     if (do_colsum && tid < BM && m0 + tid < p.M) p.colsum[m0 + tid] = csum;
     if (p.ce_part) ce_tile_partials<TM, TN, BM, BN>(p, acc, smem, m0, n0, tile_n, tid);
-#pragma unroll
-    for (int i = 0; i < TM; ++i)
-#pragma unroll
-        for (int j = 0; j < TN; ++j) {
-            const int n = n0 + wcol + j * 32 + l31;
-#pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                const int m = m0 + wrow + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * half;
-                if (m < p.M && n < p.N) p.C[(size_t)m * p.ldc + n] = epilogue_apply(p, acc[i][j][r], m, n);
-            }
-        }
+    epilogue_store<TM, TN>(p, acc, m0 + wrow, n0 + wcol, l31, half);
 }
 
 // ---- host side: tile / split-K choice ---------------------------------------------------------

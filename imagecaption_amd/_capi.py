@@ -64,6 +64,8 @@ SIGNATURES = {
     "capdec_clip_scale": (_i, [_vp, _sz, _vp, _f, _vp]),
     "capdec_adamw": (_i, [_vp, _vp, _vp, _vp, _sz, _f, _f, _f, _f, _f, _i, _vp, _f, _vp]),
     "capdec_decode_attn": (_i, [_vp, _i, _vp, _vp, _i, _vp, _i, _vp, _i, _i, _i, _i, _i, _i, _i, _f, _vp]),
+    "capdec_decode_step_workspace_bytes": (_sz, [_i, _i, _i]),
+    "capdec_decode_step": (_i, [_vp, _i, _vp, _vp, _i, _i, _i, _i, _i, _i, _i, _i, _i, _vp, _sz, _vp, _sz, _vp]),
     "capdec_greedy_select": (_i, [_vp, _i, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _vp]),
     "capdec_beam_select": (_i, [_vp, _i, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _vp]),
     "capdec_sample_select": (_i, [_vp, _i, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _i, _f, _u64, _vp]),
@@ -91,6 +93,13 @@ def lib():
             fn.restype, fn.argtypes = res, args
         _lib = l
     return _lib
+
+
+class DecodeLayer(C.Structure):
+    """capdec_decode_layer of include/capdec.h."""
+    _fields_ = [(n, C.c_void_p) for n in ("w_in", "b_in", "w_out", "b_out", "ln1_w", "ln1_b", "wc_in", "bc_in", "wc_out",
+                                          "bc_out", "ln2_w", "ln2_b", "w1", "b1", "w2", "b2", "ln3_w", "ln3_b", "cache",
+                                          "cross_kv", "cross_out")]
 
 
 class CapdecError(RuntimeError):

@@ -275,6 +275,8 @@ GemmPlan plan_gemm_f32x3(int M, int N, int K, const GemmForce& force);
 int launch_gemm_f32x3(const GemmParams& p, const GemmPlan& pl, bool AK, bool BKM, bool vec, hipStream_t st);
 GemmPlan plan_gemm_bf16s(int M, int N, int K, const GemmForce& force);
 void launch_gemm_bf16s(const GemmParams& p, const GemmPlan& pl, bool AKC, bool BKC, hipStream_t st);  // A, B: bf16
+bool gemm_skinny_ok(const GemmParams& p, bool AK, bool BKM, int dtype);  // few-row decode products (gemm_skinny.hip)
+void launch_gemm_skinny(const GemmParams& p, hipStream_t st);
 bool gemm_bf16s_dma_ok(const GemmParams& p, bool AKC, bool BKC);  // operands fit the LDS-DMA kernels (gemm_bf16s_dma.hip)
 
 }  // namespace capdec

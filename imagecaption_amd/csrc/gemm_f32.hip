@@ -471,6 +471,12 @@ extern "C" int capdec_gemm(int transA, int transB, int M, int N, int K, const vo
         CAPDEC_REQUIRE(!ep->addend || ep->ld_addend >= N, "capdec_gemm: ld_addend too small");
         CAPDEC_REQUIRE(ep->drop_p >= 0.f && ep->drop_p < 1.f, "capdec_gemm: drop_p out of range");
     }
+    // a few rows against a weight matrix (decode steps): the K-split-inside-the-workgroup kernel, unless a plan was
+    // forced (tuning hook / measured plan) for this product
+    if (gemm_skinny_ok(p, !transA, transB != 0, dtype) && !resolve_force(transA, transB, M, N, K, dtype).bm) {
+        launch_gemm_skinny(p, (hipStream_t)stream);
+        return check_launch("capdec_gemm");
+    }
     GemmPlan pl = clamp_plan(plan_for(transA, transB, M, N, K, dtype), M, N, K);
     if (dtype == CAPDEC_BF16S && pl.bn == 256 && !gemm_bf16s_dma_ok(p, !transA, transB != 0)) {
         // the 256 x 256 block exists only in the LDS-DMA form; these operands need the register-staged 256 x 128 one

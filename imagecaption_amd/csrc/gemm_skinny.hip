@@ -1,0 +1,108 @@
+// Skinny fp32 product for decode steps: C[M, N] = epilogue(A[M, K] * B[N, K]^T) with M of a few dozen rows (one
+// token per caption: the reference's sampler at its own batch sizes, ref train.py:289-412; greedy / beam steps).
+// The tiled kernel of gemm_f32.hip needs 64-row tiles and in-launch split-K to find any parallelism in such a
+// shape (8 column tiles x K slices, tickets, slab round trips: 13.6 us for 32 x 512 x 512); here one 512-thread
+// workgroup owns a 32 x 32 output block and its EIGHT WAVES SPLIT K among themselves (combined through LDS in wave
+// order: deterministic), so a 512-wide layer is 16 independent workgroups with no global hand-off at all.
+//
+// Exact fp32 (v_mfma_f32_32x32x2_f32).  The MFMA sums over k in whatever order the lanes present it, so lane
+// (l31, half) of wave w walks the CONTIGUOUS k-run  w * K/8 + half * K/16 .. + K/16  of its row -- 16-byte loads
+// straight from global memory in operand layout, no LDS staging, no wasted elements.
+#include "common.h"
+#include "gemm_common.h"
+
+namespace capdec {
+
+constexpr int SK_WAVES = 8;
+constexpr int SK_CHUNK = 8;  // float4 loads per operand in flight per lane (32 k values)
+
+__global__ __launch_bounds__(512) void gemm_skinny_f32_kernel(GemmParams p) {
+    __shared__ float red[SK_WAVES][32][33];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int l31 = lane & 31, half = lane >> 5;
+    const int n0 = blockIdx.x * 32, m0 = blockIdx.y * 32;
+    const int krun = p.K / (2 * SK_WAVES);                 // k values per lane (a multiple of 4: checked by the host)
+    const int kbeg = wave * (p.K / SK_WAVES) + half * krun;
+    const bool arow = m0 + l31 < p.M, brow = n0 + l31 < p.N;
+    const float4* ap = reinterpret_cast<const float4*>(p.A + (size_t)min(m0 + l31, p.M - 1) * p.lda + kbeg);
+    const float4* bp = reinterpret_cast<const float4*>(p.B + (size_t)min(n0 + l31, p.N - 1) * p.ldb + kbeg);
+    // what the epilogue will need goes on its way now, under the operand loads (a dependent round trip after the
+    // reduction would cost this latency-bound kernel another microsecond or two)
+    const int en = n0 + (tid & 31);
+    const float bias = (p.bias && en < p.N) ? p.bias[en] : 0.f;
+    float addv[2], auxv[2];
+#pragma unroll
+    for (int e = 0; e < 2; ++e) {
+        const int m = m0 + (tid >> 5) + 16 * e;
+        const bool ok = m < p.M && en < p.N;
+        addv[e] = (p.addend && ok) ? p.addend[(size_t)m * p.ld_addend + en] : 0.f;
+        auxv[e] = (p.act == CAPDEC_ACT_GELU_BWD && ok) ? p.aux[(size_t)m * p.ldc + en] : 0.f;
+    }
+    f32x16 acc;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+    const int nq = krun / 4;  // float4 per lane
+    // two register sets: the loads of chunk c + 1 are in flight under the MFMA chain of chunk c
+    float4 av[2][SK_CHUNK], bv[2][SK_CHUNK];
+    auto fetch = [&](int q0, float4 (&a)[SK_CHUNK], float4 (&b)[SK_CHUNK]) {
+#pragma unroll
+        for (int i = 0; i < SK_CHUNK; ++i) {
+            const bool in = q0 + i < nq;
+            a[i] = (in && arow) ? ap[q0 + i] : make_float4(0.f, 0.f, 0.f, 0.f);
+            b[i] = (in && brow) ? bp[q0 + i] : make_float4(0.f, 0.f, 0.f, 0.f);
+        }
+    };
+    auto chain = [&](const float4 (&a)[SK_CHUNK], const float4 (&b)[SK_CHUNK]) {
+#pragma unroll
+        for (int i = 0; i < SK_CHUNK; ++i) {
+            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a[i].x, b[i].x, acc, 0, 0, 0);
+            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a[i].y, b[i].y, acc, 0, 0, 0);
+            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a[i].z, b[i].z, acc, 0, 0, 0);
+            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a[i].w, b[i].w, acc, 0, 0, 0);
+        }
+    };
+    fetch(0, av[0], bv[0]);
+    for (int q0 = 0; q0 < nq; q0 += 2 * SK_CHUNK) {
+        if (q0 + SK_CHUNK < nq) fetch(q0 + SK_CHUNK, av[1], bv[1]);
+        chain(av[0], bv[0]);
+        if (q0 + SK_CHUNK < nq) {
+            if (q0 + 2 * SK_CHUNK < nq) fetch(q0 + 2 * SK_CHUNK, av[0], bv[0]);
+            chain(av[1], bv[1]);
+        }
+    }
+#pragma unroll
+    for (int r = 0; r < 16; ++r) red[wave][(r & 3) + 8 * (r >> 2) + 4 * half][l31] = acc[r];
+    __syncthreads();
+    // 1024 outputs, 512 threads: thread -> column tid & 31, rows (tid >> 5) and (tid >> 5) + 16
+    const int n = en;
+#pragma unroll
+    for (int e = 0; e < 2; ++e) {
+        const int row = (tid >> 5) + 16 * e, m = m0 + row;
+        if (m < p.M && n < p.N) {
+            float v = 0.f;
+#pragma unroll
+            for (int w = 0; w < SK_WAVES; ++w) v += red[w][row][tid & 31];
+            v += bias;
+            const size_t o = (size_t)m * p.ldc + n;
+            if (p.pre) p.pre[o] = v;
+            if (p.act == CAPDEC_ACT_GELU) v = gelu_erf(v);
+            else if (p.act == CAPDEC_ACT_GELU_BWD) v *= gelu_erf_grad(auxv[e]);
+            if (p.drop.on()) v = p.drop.apply(v, (uint32_t)m * (uint32_t)p.N + (uint32_t)n);
+            if (p.addend) v += addv[e];
+            p.C[o] = v;
+        }
+    }
+}
+
+// x[M, K] * W[N, K]^T with few rows: exact fp32, K a multiple of 64 (8 waves x 2 lane halves x one float4),
+// 16-byte aligned operands with leading dimensions that are multiples of 4; no bias-gradient sums / CE partials
+bool gemm_skinny_ok(const GemmParams& p, bool AK, bool BKM, int dtype) {
+    return dtype == CAPDEC_F32 && AK && BKM && p.M <= 64 && p.K % 64 == 0 && p.K >= 128 && p.lda % 4 == 0 && p.ldb % 4 == 0 &&
+           aligned16(p.A) && aligned16(p.B) && !p.colsum && !p.ce_part && !p.ce_lse;
+}
+
+void launch_gemm_skinny(const GemmParams& p, hipStream_t st) {
+    hipLaunchKernelGGL(gemm_skinny_f32_kernel, dim3(cdiv(p.N, 32), cdiv(p.M, 32)), dim3(512), 0, st, p);
+}
+
+}  // namespace capdec

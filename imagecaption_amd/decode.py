@@ -24,16 +24,22 @@ import math
 
 import torch
 
-from . import engine, ops
+import ctypes as C
+
+from . import _capi, engine, ops
 from ._capi import ACT_GELU, check, lib, ptr, stream
 
 START = 1
 
 
 class CaptionDecoder:
-    def __init__(self, model, dtype="fp32"):
+    def __init__(self, model, dtype="fp32", fused_step=True):
+        """``fused_step``: the decoder stack of a decode step is enqueued by ONE C call (capdec_decode_step) instead
+        of ~10 ops per layer issued from Python: same kernels, bit-identical tokens, a fraction of the host time
+        (what bounds small batches).  False keeps the op-by-op path (the parity reference of the fused call)."""
         self.model = model.eval()
         self.dtype = dtype
+        self.fused_step = fused_step
         dec = model.transformer_decoder
         self.H, self.L = dec.nhead, len(dec.layers)
         self.layers = [layer.param_dict() for layer in dec.layers]
@@ -61,6 +67,20 @@ class CaptionDecoder:
         l = lib()
         x = ops.embed_fwd(tok.view(R, 1), m.embedding.weight, st["pe"], t0=t).view(R, d)
         anc = ptr(st["anc"][st["cur"]])
+        if self.fused_step:
+            dff = st["dff"]
+            need = st["gemm_need"].get(R)
+            if need is None:
+                need = st["gemm_need"][R] = max(l.capdec_gemm_workspace_bytes(R, n, k)
+                                                for n, k in ((d, d), (2 * d, d), (dff, d), (d, dff)))
+            gws = _capi.workspace(max(need, 1), x.device, "gemm:" + ops._WS_TAG, zero=True)
+            nb = l.capdec_decode_step_workspace_bytes(R, d, dff)
+            ws = _capi.workspace(nb, x.device, "decode_step")
+            check(l.capdec_decode_step(C.cast(st["layers_c"], C.c_void_p), self.L, ptr(x), anc, R, H, d, dff, Tmax, t, W, S,
+                                       ops.COMPUTE_DTYPE, ptr(ws), ws.numel(), ptr(gws), gws.numel(), stream()),
+                  "capdec_decode_step")
+            y, _, _ = ops.layernorm_fwd(x, self.norm[0], self.norm[1], save_stats=False)
+            return engine.head_fwd(self.head, y, self.dp, None)
         for li, P in enumerate(self.layers):
             V = st["views"][li]  # weight / cache slices made once per decode call (a slice costs ~1.5 us of host time)
             q = ops.linear_fwd(x, V["wq"], V["bq"])
@@ -118,7 +138,25 @@ class CaptionDecoder:
             views.append(dict(wq=w_in[:d], bq=b_in[:d], wkv=w_in[d:], bkv=b_in[d:], wcq=wc[:d], bcq=bc[:d],
                               c2k=ptr(c2), c2v=ptr(c2[:, d:]), kvk=ptr(cross[li]),
                               kvv=None if cross[li] is None else ptr(cross[li][:, d:])))
+        # the same pointers as one C array for capdec_decode_step (the tensors stay referenced by `st` / the model)
+        layers_c = (_capi.DecodeLayer * len(self.layers))()
+        for li, P in enumerate(self.layers):
+            lc = layers_c[li]
+            lc.w_in, lc.b_in = ptr(P["self_attn.in_proj_weight"]), ptr(P["self_attn.in_proj_bias"])
+            lc.w_out, lc.b_out = ptr(P["self_attn.out_proj.weight"]), ptr(P["self_attn.out_proj.bias"])
+            lc.ln1_w, lc.ln1_b = ptr(P["norm1.weight"]), ptr(P["norm1.bias"])
+            lc.wc_in, lc.bc_in = ptr(P["multihead_attn.in_proj_weight"]), ptr(P["multihead_attn.in_proj_bias"])
+            lc.wc_out, lc.bc_out = ptr(P["multihead_attn.out_proj.weight"]), ptr(P["multihead_attn.out_proj.bias"])
+            lc.ln2_w, lc.ln2_b = ptr(P["norm2.weight"]), ptr(P["norm2.bias"])
+            lc.w1, lc.b1, lc.w2, lc.b2 = ptr(P["linear1.weight"]), ptr(P["linear1.bias"]), ptr(P["linear2.weight"]), ptr(P["linear2.bias"])
+            lc.ln3_w, lc.ln3_b = ptr(P["norm3.weight"]), ptr(P["norm3.bias"])
+            lc.cache, lc.cross_kv, lc.cross_out = ptr(cache[li]), ptr(cross[li]), ptr(cross_out[li])
+        dense = all(P[k].is_contiguous() for P in self.layers for k in engine.LAYER_KEYS)
+        if self.fused_step and not dense:
+            raise _capi.CapdecError("CaptionDecoder: capdec_decode_step needs contiguous layer parameters (fused_step=False "
+                                    "takes strided ones)")
         st = dict(N=N, W=W, R=R, S=S, Tmax=Tmax, cross_kv=cross, cross_out=cross_out, cur=0, views=views,
+                  layers_c=layers_c, dff=self.layers[0]["linear1.weight"].shape[0], gemm_need={},
                   pe=m.pos_encoder.table(),
                   cache=cache,
                   anc=[torch.arange(R, dtype=torch.int32, device=dev).view(R, 1).repeat(1, Tmax).contiguous()

@@ -295,6 +295,38 @@ int capdec_cross1_bwd(const void* g, void* dU, void* dbias_part, int B, int T, i
 int capdec_decode_attn(const void* q, int ldq, const void* k, const void* v, int ldkv, void* out, int ldo,
                        const int* anc, int R, int H, int dh, int Tmax, int t, int W, int S, float scale,
                        capdec_stream_t stream);
+/* capdec_decode_step: ONE decode step (position t) of the whole decoder stack for R rows, enqueued by a single
+ * call: per layer, q and k|v projections (k|v land in the layer's cache at position t), capdec_decode_attn over
+ * the cache, out-projection + residual, LayerNorm, the cross-attention branch (S > 1: q projection,
+ * capdec_decode_attn over cross_kv, out-projection + residual; S == 1: the per-image constant cross_out[r / W]
+ * + residual), LayerNorm, FFN (GELU) + residual, LayerNorm -- the post-norm layer of
+ * torch/nn/modules/transformer.py:1144-1153 as ref models.py:116-122 runs it, one token at a time.  x [R, d] holds
+ * the layer input (embedding + positional encoding) on entry and the last layer's output on return (the
+ * stack's final LayerNorm and the output head stay with the caller).  Exactly the launches, in the order, that
+ * a caller issuing these entry points one by one would make (imagecaption_amd/decode.py _step): bit-identical
+ * results; what it removes is the caller's per-launch host cost, which bounds small-batch decode (the reference's
+ * sampler, ref train.py:289-412, at its own batch sizes).  Tmax / W are the cache geometry of capdec_decode_attn;
+ * every pointer of a layer is a device pointer, all matrices dense (row stride = their width), fp32.
+ * workspace: capdec_decode_step_workspace_bytes(R, d, dff) bytes, 16-byte aligned; gemm_workspace: a capdec_gemm
+ * workspace (ticket words zeroed once), capdec_gemm_workspace_bytes of the largest product. */
+typedef struct capdec_decode_layer {
+    const void *w_in, *b_in;     /* self_attn.in_proj_weight [3d, d], in_proj_bias [3d] */
+    const void *w_out, *b_out;   /* self_attn.out_proj */
+    const void *ln1_w, *ln1_b;
+    const void *wc_in, *bc_in;   /* multihead_attn.in_proj (only its q block is used; S > 1) */
+    const void *wc_out, *bc_out; /* multihead_attn.out_proj (S > 1) */
+    const void *ln2_w, *ln2_b;
+    const void *w1, *b1;         /* linear1 [dff, d] */
+    const void *w2, *b2;         /* linear2 [d, dff] */
+    const void *ln3_w, *ln3_b;
+    void* cache;                 /* [rows, Tmax, 2d] self-attention K | V cache of this layer */
+    const void* cross_kv;        /* S > 1: [images * S, 2d] cross-attention K | V of the image memory */
+    const void* cross_out;       /* S == 1: [R / W, d] out_proj(v) + bias of the one memory position */
+} capdec_decode_layer;
+size_t capdec_decode_step_workspace_bytes(int R, int d, int dff);
+int capdec_decode_step(const capdec_decode_layer* layers, int L, void* x, const int* anc, int R, int H, int d, int dff,
+                       int Tmax, int t, int W, int S, int dtype, void* workspace, size_t workspace_bytes,
+                       void* gemm_workspace, size_t gemm_workspace_bytes, capdec_stream_t stream);
 int capdec_greedy_select(const void* logits, int ldl, int* done, int* seq, int64_t* next_tok, void* gap, int R, int V,
                          int Tmax, int t, capdec_stream_t stream);
 int capdec_beam_select(const void* logits, int ldl, const void* score_in, void* score_out, const int* fin_in,

@@ -329,3 +329,18 @@ def test_full_size_beam_scores_equal_teacher_forced_log_probs():
     assert bool((best[5] >= best[3] - 1e-4).all())
     b1, _ = dec.beam(feats, beam=1, max_len=L)
     assert torch.equal(b1[:, 0], dec.greedy(feats, max_len=L))
+
+
+@pytest.mark.parametrize("S", [1, 5])
+def test_one_call_decode_step_is_bit_identical_to_the_op_by_op_path(S):
+    """capdec_decode_step (the whole decoder stack of a decode step enqueued by one C call) against the same step
+    issued op by op from Python: identical greedy ids, beam ids / scores and sampler tokens, to the bit."""
+    from imagecaption_amd.decode import CaptionDecoder
+    model = _tiny_model()
+    gold = np.load(os.path.join(GOLDEN, f"tiny_S{S}.npz"))
+    feats = torch.from_numpy(gold["features"]).to(DEV)
+    one, ops_ = CaptionDecoder(model, fused_step=True), CaptionDecoder(model, fused_step=False)
+    assert torch.equal(one.greedy(feats, max_len=12), ops_.greedy(feats, max_len=12))
+    (ia, sa), (ib, sb) = one.beam(feats, beam=3, max_len=12), ops_.beam(feats, beam=3, max_len=12)
+    assert torch.equal(ia, ib) and torch.equal(sa, sb)
+    assert torch.equal(one.sample(feats, max_len=40, seed=5), ops_.sample(feats, max_len=40, seed=5))

@@ -624,3 +624,33 @@ def test_single_key_cross_branch_equals_attention_plus_out_projection(B, T, H, d
         assert float((s2.double() - want).abs().max()) < 2e-5 * scale
     a = ops.cross1_fwd(U, bo, x1, B, T, H, p, sa, p, so)
     assert torch.equal(a, s2)                                      # deterministic
+
+
+@pytest.mark.parametrize("M,N,K", [(1, 512, 512), (32, 512, 512), (32, 2048, 512), (32, 512, 2048), (33, 108, 1024),
+                                    (64, 1536, 512), (7, 40, 128)])
+def test_skinny_decode_product_with_epilogue_and_strided_output(M, N, K):
+    """Few rows against a weight matrix (decode steps) run on the K-split-inside-the-workgroup kernel
+    (csrc/gemm_skinny.hip): bias + GELU + residual epilogue, output scattered through its row stride (the K/V cache
+    write), deterministic, and equal to the tiled kernel's result up to fp32 summation order."""
+    ops = _ops()
+    from imagecaption_amd import _capi
+    from imagecaption_amd._capi import ACT_GELU
+    g = torch.Generator().manual_seed(M * 13 + N + K)
+    x, w = torch.randn(M, K, generator=g), torch.randn(N, K, generator=g) / 8
+    b, r = torch.randn(N, generator=g), torch.randn(M, N, generator=g)
+    want = gelu(x.double() @ w.double().T + b.double()) + r.double()
+    xs, ws_, bs, rs = x.to(DEV), w.to(DEV), b.to(DEV), r.to(DEV)
+    out = ops.linear_fwd(xs, ws_, bs, act=ACT_GELU, addend=rs)
+    assert relerr(out, want) < 2e-6 * math.sqrt(K)
+    assert torch.equal(out, ops.linear_fwd(xs, ws_, bs, act=ACT_GELU, addend=rs))
+    big = torch.full((M, 3, N + 8), 9.0, device=DEV)  # position 1 of a [rows, 3, N + 8] cache
+    ops.linear_fwd(xs, ws_, bs, out=big[:, 1, :N])
+    assert relerr(big[:, 1, :N], x.double() @ w.double().T + b.double()) < 2e-6 * math.sqrt(K)
+    assert torch.all(big[:, 0] == 9.0) and torch.all(big[:, 2] == 9.0) and torch.all(big[:, 1, N:] == 9.0)
+    l = _capi.lib()
+    try:  # a forced plan keeps the tiled kernel: the two agree to rounding
+        l.capdec_gemm_tune(64, 64, 1, 0)
+        tiled = ops.linear_fwd(xs, ws_, bs, act=ACT_GELU, addend=rs)
+    finally:
+        l.capdec_gemm_tune(0, 0, 0, 0)
+    assert relerr(out, tiled) < 2e-6 * math.sqrt(K)

@@ -7,7 +7,8 @@ from imagecaption_amd.decode import CaptionDecoder
 torch.manual_seed(0)
 model = ImageCaptioningModel(108, 512, 8, 6).cuda().eval()
 dec = CaptionDecoder(model)
-for n in (1, 32, 256, 1024):
+sizes = [int(a) for a in sys.argv[1:]] or [1, 32, 256, 1024]
+for n in sizes:
     feats = torch.randn(n, 768, device="cuda")
     dec.sample(feats, max_len=200, seed=1); torch.cuda.synchronize()
     t0 = time.perf_counter(); dec.sample(feats, max_len=200, seed=1); t1 = time.perf_counter(); torch.cuda.synchronize(); t2 = time.perf_counter()

@@ -78,24 +78,41 @@ __global__ __launch_bounds__(256) void decode_attn_kernel(DecodeAttnParams p) {
     const int nkeys = p.anc ? p.t + 1 : p.S;
     const float4 q4 = scaled_q(p.q + (size_t)r * p.ldq + h * DH + e4 * 4, p.scale);
     RowAttn st{-INFINITY, 0.f, make_float4(0.f, 0.f, 0.f, 0.f)};
-    for (int j0 = 0; j0 < nkeys; j0 += KPI) {
-        const int j = j0 + g;
-        const bool valid = j < nkeys;
-        size_t row = 0;
-        if (valid) {
-            if (p.anc) {
-                const int slot = j == p.t ? r : p.anc[(size_t)r * p.Tmax + j];
-                row = (size_t)slot * p.Tmax + j;
-            } else {
-                row = (size_t)(r / p.W) * p.S + j;
+    // UNR passes per trip: their ancestry look-ups, then their K / V loads, are all issued before the first update, so
+    // a trip costs one dependent round trip instead of UNR (the loop is latency-bound: one wave walks ~t keys); the
+    // updates run in key order as before -- the same arithmetic, bit for bit.
+    constexpr int UNR = 4;
+    for (int j0 = 0; j0 < nkeys; j0 += KPI * UNR) {
+        bool valid[UNR];
+        size_t row[UNR];
+#pragma unroll
+        for (int u = 0; u < UNR; ++u) {
+            const int j = j0 + u * KPI + g;
+            valid[u] = j < nkeys;
+            row[u] = 0;
+            if (valid[u]) {
+                if (p.anc) {
+                    const int slot = j == p.t ? r : p.anc[(size_t)r * p.Tmax + j];
+                    row[u] = (size_t)slot * p.Tmax + j;
+                } else {
+                    row[u] = (size_t)(r / p.W) * p.S + j;
+                }
             }
         }
-        float4 k4 = make_float4(0.f, 0.f, 0.f, 0.f), v4 = k4;
-        if (valid) {
-            k4 = *reinterpret_cast<const float4*>(p.k + row * p.ldkv + h * DH + e4 * 4);
-            v4 = *reinterpret_cast<const float4*>(p.v + row * p.ldkv + h * DH + e4 * 4);
+        float4 k4[UNR], v4[UNR];
+#pragma unroll
+        for (int u = 0; u < UNR; ++u) {
+            k4[u] = make_float4(0.f, 0.f, 0.f, 0.f);
+            v4[u] = k4[u];
+            if (valid[u]) {
+                k4[u] = *reinterpret_cast<const float4*>(p.k + row[u] * p.ldkv + h * DH + e4 * 4);
+                v4[u] = *reinterpret_cast<const float4*>(p.v + row[u] * p.ldkv + h * DH + e4 * 4);
+            }
         }
-        row_attn_update<LPK>(st, q4, k4, v4, valid);
+#pragma unroll
+        for (int u = 0; u < UNR; ++u) {
+            if (j0 + u * KPI < nkeys) row_attn_update<LPK>(st, q4, k4[u], v4[u], valid[u]);
+        }
     }
     const float4 o4 = row_attn_finish<LPK>(st);
     if (g == 0) *reinterpret_cast<float4*>(p.out + (size_t)r * p.ldo + h * DH + e4 * 4) = o4;

@@ -36,6 +36,10 @@ typedef short s16x4 __attribute__((ext_vector_type(4)));
 typedef short s16x8 __attribute__((ext_vector_type(8)));
 
 constexpr int DBK = 64;
+#ifndef CAPDEC_DMA_MGROUP
+#define CAPDEC_DMA_MGROUP 8
+#endif
+constexpr int DMA_MGROUP = CAPDEC_DMA_MGROUP;  // row tiles that share a sweep over the column tiles (L2 reuse of their A panel)
 
 #define CAPDEC_GLDS16(gptr, lptr) \
     __builtin_amdgcn_global_load_lds((const void __attribute__((address_space(1)))*)(gptr), \
@@ -102,9 +106,9 @@ void gemm_bf16s_dma_kernel(GemmParams p) {
     int tile_m, tile_n;
     {
         const int tiles_m = nwg / p.tiles_n;
-        const int per_group = 8 * p.tiles_n;
-        const int gid = wg / per_group, first_m = gid * 8;
-        const int gsz = min(tiles_m - first_m, 8);
+        const int per_group = DMA_MGROUP * p.tiles_n;
+        const int gid = wg / per_group, first_m = gid * DMA_MGROUP;
+        const int gsz = min(tiles_m - first_m, DMA_MGROUP);
         const int in_g = wg - gid * per_group;
         tile_m = first_m + in_g % gsz;
         tile_n = in_g / gsz;

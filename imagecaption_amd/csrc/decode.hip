@@ -493,7 +493,10 @@ extern "C" int capdec_beam_select(const void* logits, int ldl, const void* score
                    "capdec_beam_select: bad shape N=%d W=%d (max %d) V=%d t=%d Tmax=%d", N, W, MAXW, V, t, Tmax);
     CAPDEC_REQUIRE((uint64_t)W * V < (1ull << 31), "capdec_beam_select: W*V too large");
     // rows that can be staged in LDS (float4-readable, at most 60 KB: two or more workgroups per CU and no opt-in
-    // for large dynamic LDS needed) take the one-read kernel
+    // for large dynamic LDS needed) take the one-read kernel.  Measured for V = 30 000 (tools/beam_select_time.py,
+    // 2048 images x 5 beams): staging the 120 KB row (large-LDS opt-in, ONE workgroup per CU) takes 2.31 ms against
+    // 1.09 ms for the re-reading kernel -- the kernel is bound by its insertion network (vector issue), not by the
+    // logits reads, so the lost occupancy costs more than the two saved reads; such rows stay on the re-reading path
     const size_t lds = (size_t)V * sizeof(float);
     const bool stage = V % 4 == 0 && ldl % 4 == 0 && aligned16(logits) && lds <= 60 * 1024;
 #define CAPDEC_BEAM(ST, LW) \

@@ -20,7 +20,8 @@ _vp, _i, _f, _u64, _sz = C.c_void_p, C.c_int, C.c_float, C.c_uint64, C.c_size_t
 class Epilogue(C.Structure):
     _fields_ = [("bias", _vp), ("addend", _vp), ("pre", _vp), ("aux", _vp), ("colsum", _vp),
                 ("ld_addend", _i), ("act", _i), ("drop_p", _f), ("drop_seed", _u64),
-                ("ce_partials", _vp), ("ce_lse", _vp), ("ce_targets", _vp), ("ce_eps", _f), ("ce_grad_scale", _f)]
+                ("ce_partials", _vp), ("ce_lse", _vp), ("ce_targets", _vp), ("ce_eps", _f), ("ce_grad_scale", _f),
+                ("c16", _vp), ("ldc16", _i)]
 
 
 # name -> (restype, argtypes); mirrors include/capdec.h one to one
@@ -50,6 +51,9 @@ SIGNATURES = {
     "capdec_attn_fwd": (_i, [_vp, _i, _vp, _i, _vp, _i, _vp, _i, _vp, _i, _i, _i, _i, _i, _i, _f, _f, _u64, _vp]),
     "capdec_attn_bwd": (_i, [_vp, _i, _vp, _i, _vp, _i, _vp, _i, _vp, _i, _vp, _vp, _vp, _i, _vp, _i, _vp, _i,
                              _i, _i, _i, _i, _i, _i, _f, _f, _u64, _vp]),
+    "capdec_attn_fwd_kv16": (_i, [_vp, _i, _vp, _i, _vp, _i, _vp, _i, _vp, _i, _i, _i, _i, _i, _i, _f, _f, _u64, _vp]),
+    "capdec_attn_bwd_kv16": (_i, [_vp, _i, _vp, _i, _vp, _i, _vp, _i, _vp, _i, _vp, _vp, _vp, _i, _vp, _i, _vp, _i,
+                                  _i, _i, _i, _i, _i, _i, _f, _f, _u64, _vp]),
     "capdec_attn_bwd_dkv16": (_i, [_vp, _i, _vp, _i, _vp, _i, _vp, _i, _vp, _i, _vp, _vp, _vp, _i, _vp, _i, _vp, _i,
                                    _i, _i, _i, _i, _i, _i, _f, _f, _u64, _vp]),
     "capdec_softmax_ce": (_i, [_vp, _i, _vp, _vp, _vp, _i, _i, _i, _f, _f, _vp]),

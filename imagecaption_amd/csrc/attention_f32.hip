@@ -27,6 +27,7 @@ struct AttnParams {
     int ldq, ldk, ldv, ldo, lddo, lddq, lddk, lddv;
     int B, H, Tq, Tk, causal;
     int dkv_bf16;  // dk / dv point to bf16 matrices (lddk / lddv in bf16 elements): capdec_attn_bwd_dkv16
+    int kv_bf16;   // k / v point to bf16 matrices (ldk / ldv in bf16 elements): capdec_attn_*_kv16
     float scale;
     Dropout drop;
 };
@@ -66,25 +67,45 @@ __device__ __forceinline__ void attn_item(int n_bh, int n_tiles, bool longest_fi
 // A 32 x DH tile moves global -> registers (coalesced: 16 consecutive lanes read one 256-B row
 // piece) -> LDS, in two separate steps so the global loads of the NEXT tile can be in flight
 // while the current one is being multiplied (register prefetch, no extra LDS).
+// b16 (wave-uniform): the matrix is bf16 (g points at its first element, ldg in bf16 elements); the four elements
+// (8 B) of a lane stay PACKED in .x / .y of its register slot -- nothing here depends on the loaded value, so the
+// load stays in flight under the MFMAs as the fp32 ones do -- and tile_lstore widens them on the way into LDS.
 template <int DH>
-__device__ __forceinline__ void tile_gload(float4* regs, const float* g, int ldg, int row0, int T, int lane) {
+__device__ __forceinline__ void tile_gload(float4* regs, const float* g, int ldg, int row0, int T, int lane, bool b16 = false) {
 #pragma unroll
     for (int i = 0; i < DH / 8; ++i) {
         const int f = lane + 64 * i;
         const int row = f / (DH / 4), c4 = f % (DH / 4);
         const int t = row0 + row;
         regs[i] = make_float4(0.f, 0.f, 0.f, 0.f);
-        if (t < T) regs[i] = *reinterpret_cast<const float4*>(g + (size_t)t * ldg + c4 * 4);
+        if (t < T) {
+            if (b16) {
+                const float2 u = *reinterpret_cast<const float2*>(reinterpret_cast<const __bf16*>(g) + (size_t)t * ldg + c4 * 4);
+                regs[i].x = u.x;
+                regs[i].y = u.y;
+            } else {
+                regs[i] = *reinterpret_cast<const float4*>(g + (size_t)t * ldg + c4 * 4);
+            }
+        }
     }
 }
+// first element of head h of image b in a K / V matrix that is fp32 or (b16) bf16
+__device__ __forceinline__ const float* kv_base(const float* m, size_t elem_off, bool b16) {
+    return b16 ? reinterpret_cast<const float*>(reinterpret_cast<const __bf16*>(m) + elem_off) : m + elem_off;
+}
 template <int DH>
-__device__ __forceinline__ void tile_lstore(float* s, const float4* regs, float mul, int lane) {
+__device__ __forceinline__ void tile_lstore(float* s, const float4* regs, float mul, int lane, bool b16 = false) {
     constexpr int LD = DH + 4;
 #pragma unroll
     for (int i = 0; i < DH / 8; ++i) {
         const int f = lane + 64 * i;
         const int row = f / (DH / 4), c4 = f % (DH / 4);
         float4 v = regs[i];
+        if (b16) {  // .x / .y hold four packed bf16 values (tile_gload): widen exactly
+            const unsigned int ux = __float_as_uint(v.x), uy = __float_as_uint(v.y);
+            v = make_float4(__uint_as_float(ux << 16), __uint_as_float(ux & 0xffff0000u), __uint_as_float(uy << 16),
+                            __uint_as_float(uy & 0xffff0000u));
+        }
         v.x *= mul; v.y *= mul; v.z *= mul; v.w *= mul;
         *reinterpret_cast<float4*>(&s[row * LD + c4 * 4]) = v;
     }
@@ -177,8 +198,9 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(DH <= 64 ? 3
     const int b = bh / p.H, h = bh % p.H;
     const int q0 = qt * 32, off = p.Tk - p.Tq;
     const float* qg = p.q + (size_t)b * p.Tq * p.ldq + h * DH;
-    const float* kg = p.k + (size_t)b * p.Tk * p.ldk + h * DH;
-    const float* vg = p.v + (size_t)b * p.Tk * p.ldv + h * DH;
+    const bool b16 = p.kv_bf16 != 0;
+    const float* kg = kv_base(p.k, (size_t)b * p.Tk * p.ldk + h * DH, b16);
+    const float* vg = kv_base(p.v, (size_t)b * p.Tk * p.ldv + h * DH, b16);
 
     // Diagnostic builds only (tools/attn_stamps.py; never in the shipped library): -DCAPDEC_ATTN_STAMPS records
     // s_memtime at the phase boundaries of every wave, -DCAPDEC_ATTN_NOMMA replaces the matrix products by a few
@@ -203,7 +225,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(DH <= 64 ? 3
     if (p.causal) kmax = min(p.Tk, q0 + 31 + off + 1);
     const int nkt = kmax > 0 ? (kmax + 31) / 32 : 0;
     tile_gload<DH>(qf, qg, p.ldq, q0, p.Tq, lane);
-    if (nkt > 0) tile_gload<DH>(tr, kg, p.ldk, 0, p.Tk, lane);
+    if (nkt > 0) tile_gload<DH>(tr, kg, p.ldk, 0, p.Tk, lane, b16);
     tile_lstore<DH>(Ts, qf, p.scale, lane);
     STAMP();  // 1: Q arrived
     __syncthreads();
@@ -217,10 +239,10 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(DH <= 64 ? 3
     for (int kt = 0; kt < nkt; ++kt) {
         const int k0 = kt * 32;
         __syncthreads();
-        tile_lstore<DH>(Ts, tr, 1.f, lane);  // K tile
+        tile_lstore<DH>(Ts, tr, 1.f, lane, b16);  // K tile
         if (kt == 0) STAMP();  // 2: K0 arrived and stored
         __syncthreads();
-        tile_gload<DH>(tr, vg, p.ldv, k0, p.Tk, lane);  // V tile flies under the score MFMAs
+        tile_gload<DH>(tr, vg, p.ldv, k0, p.Tk, lane, b16);  // V tile flies under the score MFMAs
 #ifdef CAPDEC_ATTN_NOMMA
         f32x16 s;
         for (int r = 0; r < 16; ++r) s[r] = Ts[l31 * LD + r] * qf[r % (DH / 8)].x;
@@ -261,10 +283,10 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(DH <= 64 ? 3
         if (kt == 0) STAMP();  // 4: softmax + dropout done
         __syncthreads();  // every lane is done reading K
         if (lane < 32) line[lane] = alpha;
-        tile_lstore<DH>(Ts, tr, 1.f, lane);  // V tile
+        tile_lstore<DH>(Ts, tr, 1.f, lane, b16);  // V tile
         if (kt == 0) STAMP();  // 5: V0 arrived and stored
         __syncthreads();
-        if (kt + 1 < nkt) tile_gload<DH>(tr, kg, p.ldk, k0 + 32, p.Tk, lane);  // next K under the P V MFMAs
+        if (kt + 1 < nkt) tile_gload<DH>(tr, kg, p.ldk, k0 + 32, p.Tk, lane, b16);  // next K under the P V MFMAs
 #pragma unroll
         for (int g = 0; g < 4; ++g) {
             const float4 t = *reinterpret_cast<const float4*>(&line[8 * g + 4 * half]);
@@ -333,8 +355,9 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2))) void at
     const int q0 = qt * 32, off = p.Tk - p.Tq;
     const int query = q0 + l31;
     const float* qg = p.q + (size_t)b * p.Tq * p.ldq + h * DH;
-    const float* kg = p.k + (size_t)b * p.Tk * p.ldk + h * DH;
-    const float* vg = p.v + (size_t)b * p.Tk * p.ldv + h * DH;
+    const bool b16 = p.kv_bf16 != 0;
+    const float* kg = kv_base(p.k, (size_t)b * p.Tk * p.ldk + h * DH, b16);
+    const float* vg = kv_base(p.v, (size_t)b * p.Tk * p.ldv + h * DH, b16);
     const float* og = p.o + (size_t)b * p.Tq * p.ldo + h * DH;
     const float* dog = p.dout + (size_t)b * p.Tq * p.lddo + h * DH;
 
@@ -364,8 +387,8 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2))) void at
     const float lse = query < p.Tq ? p.lse[(size_t)bh * p.Tq + query] : INFINITY;
     if (lane < 32 && query < p.Tq) p.delta[(size_t)bh * p.Tq + query] = dsum;
     if (nkt > 0) {
-        tile_gload<DH>(kr, kg, p.ldk, 0, p.Tk, lane);
-        tile_gload<DH>(vr, vg, p.ldv, 0, p.Tk, lane);
+        tile_gload<DH>(kr, kg, p.ldk, 0, p.Tk, lane, b16);
+        tile_gload<DH>(vr, vg, p.ldv, 0, p.Tk, lane, b16);
     }
 
     f32x16 dqacc[DH / 32];
@@ -376,12 +399,12 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2))) void at
     for (int kt = 0; kt < nkt; ++kt) {
         const int k0 = kt * 32;
         __syncthreads();
-        tile_lstore<DH>(Ks, kr, 1.f, lane);
-        tile_lstore<DH>(Vs, vr, 1.f, lane);
+        tile_lstore<DH>(Ks, kr, 1.f, lane, b16);
+        tile_lstore<DH>(Vs, vr, 1.f, lane, b16);
         __syncthreads();
         if (kt + 1 < nkt) {
-            tile_gload<DH>(kr, kg, p.ldk, k0 + 32, p.Tk, lane);
-            tile_gload<DH>(vr, vg, p.ldv, k0 + 32, p.Tk, lane);
+            tile_gload<DH>(kr, kg, p.ldk, k0 + 32, p.Tk, lane, b16);
+            tile_gload<DH>(vr, vg, p.ldv, k0 + 32, p.Tk, lane, b16);
         }
         f32x16 s = mma_lds_reg<DH>(Ks, qf, l31, half);    // S^T[key][query]
         f32x16 dp = mma_lds_reg<DH>(Vs, dof, l31, half);  // dP^T[key][query]
@@ -428,16 +451,17 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2))) void at
     const int k0 = kt * 32, off = p.Tk - p.Tq;
     const int key = k0 + l31;
     const float* qg = p.q + (size_t)b * p.Tq * p.ldq + h * DH;
-    const float* kg = p.k + (size_t)b * p.Tk * p.ldk + h * DH;
-    const float* vg = p.v + (size_t)b * p.Tk * p.ldv + h * DH;
+    const bool b16 = p.kv_bf16 != 0;
+    const float* kg = kv_base(p.k, (size_t)b * p.Tk * p.ldk + h * DH, b16);
+    const float* vg = kv_base(p.v, (size_t)b * p.Tk * p.ldv + h * DH, b16);
     const float* dog = p.dout + (size_t)b * p.Tq * p.lddo + h * DH;
 
     float4 kf[DH / 8], vf[DH / 8], qr[DH / 8], dr[DH / 8];
     // this wave's K and V tile: full rows -> LDS -> fragments (kept in registers for the whole q loop)
-    tile_gload<DH>(kf, kg, p.ldk, k0, p.Tk, lane);
-    tile_gload<DH>(vf, vg, p.ldv, k0, p.Tk, lane);
-    tile_lstore<DH>(Qs, kf, 1.f, lane);
-    tile_lstore<DH>(dOs, vf, 1.f, lane);
+    tile_gload<DH>(kf, kg, p.ldk, k0, p.Tk, lane, b16);
+    tile_gload<DH>(vf, vg, p.ldv, k0, p.Tk, lane, b16);
+    tile_lstore<DH>(Qs, kf, 1.f, lane, b16);
+    tile_lstore<DH>(dOs, vf, 1.f, lane, b16);
     __syncthreads();
     lds_frag<DH>(kf, Qs, l31, half);
     lds_frag<DH>(vf, dOs, l31, half);
@@ -604,10 +628,11 @@ static bool ok_mat(const void* p, int ld, int H, int dh) { return p && aligned16
 
 using namespace capdec;
 
-extern "C" int capdec_attn_fwd(const void* q, int ldq, const void* k, int ldk, const void* v, int ldv, void* o, int ldo,
-                               void* lse, int B, int H, int Tq, int Tk, int dh, int causal, float scale, float drop_p,
-                               uint64_t drop_seed, capdec_stream_t stream) {
+static int attn_fwd_impl(const void* q, int ldq, const void* k, int ldk, const void* v, int ldv, void* o, int ldo,
+                         void* lse, int B, int H, int Tq, int Tk, int dh, int causal, float scale, float drop_p,
+                         uint64_t drop_seed, capdec_stream_t stream, int kv_bf16) {
     if (int rc = check_common("capdec_attn_fwd", B, H, Tq, Tk, dh)) return rc;
+    CAPDEC_REQUIRE(!kv_bf16 || Tk > 1, "capdec_attn_fwd_kv16: needs Tk > 1");
     CAPDEC_REQUIRE(ok_mat(q, ldq, H, dh) && ok_mat(k, ldk, H, dh) && ok_mat(v, ldv, H, dh) && ok_mat(o, ldo, H, dh),
                    "capdec_attn_fwd: operands must be non-null, 16-byte aligned, ld %% 4 == 0, ld >= H*dh");
     AttnParams p;
@@ -615,6 +640,7 @@ extern "C" int capdec_attn_fwd(const void* q, int ldq, const void* k, int ldk, c
     p.q = (const float*)q; p.k = (const float*)k; p.v = (const float*)v; p.out = (float*)o; p.lse = (float*)lse;
     p.ldq = ldq; p.ldk = ldk; p.ldv = ldv; p.ldo = ldo;
     p.B = B; p.H = H; p.Tq = Tq; p.Tk = Tk; p.causal = causal; p.scale = scale;
+    p.kv_bf16 = kv_bf16;
     p.drop = make_dropout(drop_p, drop_seed);
     const dim3 grid(B * H * ((Tq + 31) / 32));
     hipStream_t st = (hipStream_t)stream;
@@ -629,10 +655,23 @@ extern "C" int capdec_attn_fwd(const void* q, int ldq, const void* k, int ldk, c
     return check_launch("capdec_attn_fwd");
 }
 
+extern "C" int capdec_attn_fwd(const void* q, int ldq, const void* k, int ldk, const void* v, int ldv, void* o, int ldo,
+                               void* lse, int B, int H, int Tq, int Tk, int dh, int causal, float scale, float drop_p,
+                               uint64_t drop_seed, capdec_stream_t stream) {
+    return attn_fwd_impl(q, ldq, k, ldk, v, ldv, o, ldo, lse, B, H, Tq, Tk, dh, causal, scale, drop_p, drop_seed, stream, 0);
+}
+
+extern "C" int capdec_attn_fwd_kv16(const void* q, int ldq, const void* k16, int ldk, const void* v16, int ldv, void* o,
+                                    int ldo, void* lse, int B, int H, int Tq, int Tk, int dh, int causal, float scale,
+                                    float drop_p, uint64_t drop_seed, capdec_stream_t stream) {
+    return attn_fwd_impl(q, ldq, k16, ldk, v16, ldv, o, ldo, lse, B, H, Tq, Tk, dh, causal, scale, drop_p, drop_seed, stream, 1);
+}
+
 static int attn_bwd_impl(const void* q, int ldq, const void* k, int ldk, const void* v, int ldv, const void* o,
                          int ldo, const void* dout, int lddo, const void* lse, void* delta, void* dq, int lddq,
                          void* dk, int lddk, void* dv, int lddv, int B, int H, int Tq, int Tk, int dh, int causal,
-                         float scale, float drop_p, uint64_t drop_seed, capdec_stream_t stream, int dkv_bf16) {
+                         float scale, float drop_p, uint64_t drop_seed, capdec_stream_t stream, int dkv_bf16,
+                         int kv_bf16 = 0) {
     if (int rc = check_common("capdec_attn_bwd", B, H, Tq, Tk, dh)) return rc;
     CAPDEC_REQUIRE(ok_mat(q, ldq, H, dh) && ok_mat(k, ldk, H, dh) && ok_mat(v, ldv, H, dh) && ok_mat(o, ldo, H, dh) &&
                        ok_mat(dout, lddo, H, dh) && (ok_mat(dq, lddq, H, dh) || (Tk == 1 && !dq)) &&
@@ -643,6 +682,8 @@ static int attn_bwd_impl(const void* q, int ldq, const void* k, int ldk, const v
     AttnParams p;
     memset(&p, 0, sizeof(p));
     p.dkv_bf16 = dkv_bf16;
+    p.kv_bf16 = kv_bf16;
+    CAPDEC_REQUIRE(!kv_bf16 || Tk > 1, "capdec_attn_bwd_kv16: needs Tk > 1");
     p.q = (const float*)q; p.k = (const float*)k; p.v = (const float*)v; p.o = (const float*)o;
     p.dout = (const float*)dout; p.lse = (float*)lse; p.delta = (float*)delta;
     p.dq = (float*)dq; p.dk = (float*)dk; p.dv = (float*)dv;
@@ -682,4 +723,12 @@ extern "C" int capdec_attn_bwd_dkv16(const void* q, int ldq, const void* k, int 
                                      int causal, float scale, float drop_p, uint64_t drop_seed, capdec_stream_t stream) {
     return attn_bwd_impl(q, ldq, k, ldk, v, ldv, o, ldo, dout, lddo, lse, delta, dq, lddq, dk16, lddk, dv16, lddv, B, H, Tq,
                          Tk, dh, causal, scale, drop_p, drop_seed, stream, 1);
+}
+
+extern "C" int capdec_attn_bwd_kv16(const void* q, int ldq, const void* k16, int ldk, const void* v16, int ldv, const void* o,
+                                    int ldo, const void* dout, int lddo, const void* lse, void* delta, void* dq, int lddq,
+                                    void* dk16, int lddk, void* dv16, int lddv, int B, int H, int Tq, int Tk, int dh,
+                                    int causal, float scale, float drop_p, uint64_t drop_seed, capdec_stream_t stream) {
+    return attn_bwd_impl(q, ldq, k16, ldk, v16, ldv, o, ldo, dout, lddo, lse, delta, dq, lddq, dk16, lddk, dv16, lddv, B, H,
+                         Tq, Tk, dh, causal, scale, drop_p, drop_seed, stream, 1, 1);
 }

@@ -28,6 +28,8 @@ struct GemmParams {
     const float* ce_lse;    // backward: A holds the LOGITS; the A loaders turn them into dlogits on their way to LDS
     const int64_t* ce_y;    //   dlogits[row, col] = gs * (exp(z - lse[row]) - eps/V - (1 - eps) * [col == y[row]])
     float ce_gs, ce_u, ce_w;  // grad scale, eps / V, 1 - eps
+    __bf16* c16;            // if set: the result goes THERE as bf16 (row stride ldc16), not to C
+    int ldc16;
 };
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
@@ -173,7 +175,8 @@ __device__ __forceinline__ void epilogue_store(const GemmParams& p, const f32x16
                         else if (gbwd) v *= gelu_erf_grad(has_add ? p.aux[o] : st[cur][e]);
                         if (p.drop.on()) v = p.drop.apply(v, (uint32_t)m * (uint32_t)p.N + (uint32_t)n);
                         if (has_add) v += st[cur][e];
-                        p.C[o] = v;
+                        if (p.c16) p.c16[(size_t)m * p.ldc16 + n] = (__bf16)v;
+                        else p.C[o] = v;
                     }
                 }
             }

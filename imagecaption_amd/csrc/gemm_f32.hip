@@ -427,7 +427,7 @@ extern "C" int capdec_gemm(int transA, int transB, int M, int N, int K, const vo
     CAPDEC_REQUIRE(dtype == CAPDEC_F32 || dtype == CAPDEC_BF16 || dtype == CAPDEC_F32X3 || dtype == CAPDEC_BF16S,
                    "capdec_gemm: dtype %d not supported", dtype);
     CAPDEC_REQUIRE(M > 0 && N > 0 && K > 0, "capdec_gemm: bad shape M=%d N=%d K=%d", M, N, K);
-    CAPDEC_REQUIRE(A && B && C, "capdec_gemm: null operand");
+    CAPDEC_REQUIRE(A && B && (C || (ep && ep->c16)), "capdec_gemm: null operand");
     CAPDEC_REQUIRE(lda >= (transA ? M : K) && ldb >= (transB ? K : N) && ldc >= N,
                    "capdec_gemm: leading dimension too small (lda=%d ldb=%d ldc=%d)", lda, ldb, ldc);
     // the epilogue's dropout mask is indexed by the 32-bit element number m*N + n: only products WITH dropout are bound
@@ -451,6 +451,9 @@ extern "C" int capdec_gemm(int transA, int transB, int M, int N, int K, const vo
         p.ld_addend = ep->ld_addend;
         p.act = ep->act;
         p.drop = make_dropout(ep->drop_p, ep->drop_seed);
+        p.c16 = (__bf16*)ep->c16;
+        p.ldc16 = ep->ldc16;
+        CAPDEC_REQUIRE(!p.c16 || (ep->ldc16 >= N && !ep->ce_partials), "capdec_gemm: c16 needs ldc16 >= N (and no ce_partials)");
         p.ce_part = (float4*)ep->ce_partials;
         p.ce_lse = (const float*)ep->ce_lse;
         p.ce_y = ep->ce_targets;

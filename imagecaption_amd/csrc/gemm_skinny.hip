@@ -98,7 +98,7 @@ __global__ __launch_bounds__(512) void gemm_skinny_f32_kernel(GemmParams p) {
 // 16-byte aligned operands with leading dimensions that are multiples of 4; no bias-gradient sums / CE partials
 bool gemm_skinny_ok(const GemmParams& p, bool AK, bool BKM, int dtype) {
     return dtype == CAPDEC_F32 && AK && BKM && p.M <= 64 && p.K % 64 == 0 && p.K >= 128 && p.lda % 4 == 0 && p.ldb % 4 == 0 &&
-           aligned16(p.A) && aligned16(p.B) && !p.colsum && !p.ce_part && !p.ce_lse;
+           aligned16(p.A) && aligned16(p.B) && !p.colsum && !p.ce_part && !p.ce_lse && !p.c16;
 }
 
 void launch_gemm_skinny(const GemmParams& p, hipStream_t st) {

@@ -195,6 +195,9 @@ def stack_fwd(layers, norm_w, norm_b, x, mem, B, T, S, H, causal, dp, save):
     if len(layers) > 1 and mem.shape[0] >= 1024:
         w_all = torch.cat([P["multihead_attn.in_proj_weight"][d:] for P in layers])
         b_all = torch.cat([P["multihead_attn.in_proj_bias"][d:] for P in layers])
+        # (bf16 storage: writing this block as bf16 for capdec_attn_*_kv16 was measured at C3 -- attention 4.2 -> 4.45 ms
+        # per step, step unchanged: the attention kernels are bound by their one-round structure, not by the K / V
+        # bytes -- so the block stays fp32; ops.linear_fwd(out=<bf16 view>) is how to do it)
         kv_all = ops.linear_fwd(mem, w_all, b_all)
     for l, P in enumerate(layers):
         sv = {} if save is not None else None

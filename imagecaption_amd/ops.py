@@ -329,7 +329,11 @@ def gemm(a, b, trans_a, trans_b, out=None, bias=None, addend=None, pre=None, aux
         raise _capi.CapdecError(f"gemm: inner dimensions differ ({K} vs {Kb})")
     if out is None:
         out = torch.empty((M, N), dtype=torch.float32, device=a.device)
-    _mat(out, "gemm.out")
+    out16 = out.dtype == torch.bfloat16  # the result is wanted as bf16 only (capdec_epilogue.c16)
+    if out16:
+        _bf16_operand(out, "gemm.out")
+    else:
+        _mat(out, "gemm.out")
     if tuple(out.shape) != (M, N):
         raise _capi.CapdecError(f"gemm: out is {tuple(out.shape)}, expected {(M, N)}")
     if TUNE_RECORD is not None:
@@ -348,6 +352,10 @@ def gemm(a, b, trans_a, trans_b, out=None, bias=None, addend=None, pre=None, aux
     if colsum is not None and colsum.numel() != M:
         raise _capi.CapdecError("gemm: colsum must have M elements")
     ep.act, ep.drop_p, ep.drop_seed = act, float(drop_p), int(seed) & 0xFFFFFFFFFFFFFFFF
+    if out16:
+        if pre is not None or aux is not None or ce_partials is not None:
+            raise _capi.CapdecError("gemm: a bf16 result cannot be combined with pre / aux / ce_partials")
+        ep.c16, ep.ldc16 = ptr(out), out.stride(0)
     l = lib()
     if ce_partials is not None:
         tiles = l.capdec_gemm_ce_tiles(M, N, K, COMPUTE_DTYPE)
@@ -365,7 +373,7 @@ def gemm(a, b, trans_a, trans_b, out=None, bias=None, addend=None, pre=None, aux
     if need is None:
         need = _WS_NEED[(M, N, K)] = l.capdec_gemm_workspace_bytes(M, N, K)
     ws = _capi.workspace(need, a.device, "gemm:" + _WS_TAG, zero=True) if need else None
-    args = (int(trans_a), int(trans_b), M, N, K, ptr(a), a.stride(0), ptr(b), b.stride(0), ptr(out), out.stride(0),
+    args = (int(trans_a), int(trans_b), M, N, K, ptr(a), a.stride(0), ptr(b), b.stride(0), None if out16 else ptr(out), out.stride(0),
             C.byref(ep), COMPUTE_DTYPE, ptr(ws), ws.numel() if ws is not None else 0, stream())
     if PROFILE is None:  # the common case: no per-launch events, no label formatting
         check(l.capdec_gemm(*args), "capdec_gemm")
@@ -531,16 +539,23 @@ def cross1_bwd(g, B, T, H, attn_p=0.0, attn_seed=0):
 
 
 def attn_fwd(q, k, v, B, H, Tq, Tk, causal, drop_p=0.0, seed=0, out=None, save_lse=True):
-    """q [B*Tq, >=H*dh] / k, v [B*Tk, ...] row-strided 2-D views; returns o [B*Tq, H*dh], lse [B,H,Tq]."""
-    _mat(q, "attn.q"), _mat(k, "attn.k"), _mat(v, "attn.v")
+    """q [B*Tq, >=H*dh] / k, v [B*Tk, ...] row-strided 2-D views; returns o [B*Tq, H*dh], lse [B,H,Tq].
+    bf16 ``k`` / ``v`` (both, Tk > 1; views of a block a GEMM wrote as bf16) go through capdec_attn_fwd_kv16."""
+    _mat(q, "attn.q")
+    kv16 = k.dtype == torch.bfloat16
+    if kv16:
+        _bf16_operand(k, "attn.k"), _bf16_operand(v, "attn.v")
+    else:
+        _mat(k, "attn.k"), _mat(v, "attn.v")
+    fwd = lib().capdec_attn_fwd_kv16 if kv16 else lib().capdec_attn_fwd
     D = q.shape[1]
     dh = D // H
     o = torch.empty((B * Tq, D), dtype=torch.float32, device=q.device) if out is None else out
     lse = torch.empty((B, H, Tq), dtype=torch.float32, device=q.device) if save_lse else None
     # algorithmic bytes (SURVEY.md 8d): read Q, K, V, write O
     with _Timed(f"attn_fwd_{'causal' if causal else 'cross'}_{Tq}x{Tk}", 4.0 * B * H * Tq * Tk * dh,
-                4.0 * B * D * (2 * Tq + 2 * Tk)):
-        check(lib().capdec_attn_fwd(ptr(q), q.stride(0), ptr(k), k.stride(0), ptr(v), v.stride(0), ptr(o), o.stride(0),
+                4.0 * B * D * (2 * Tq + (1 if kv16 else 2) * Tk)):
+        check(fwd(ptr(q), q.stride(0), ptr(k), k.stride(0), ptr(v), v.stride(0), ptr(o), o.stride(0),
                                     ptr(lse), B, H, Tq, Tk, dh, int(causal), 1.0 / math.sqrt(dh), float(drop_p),
                                     int(seed), stream()), "capdec_attn_fwd")
     return o, lse
@@ -563,9 +578,13 @@ def attn_bwd(q, k, v, o, do, lse, B, H, Tq, Tk, causal, drop_p=0.0, seed=0, dq=N
     kv16 = dk.dtype == torch.bfloat16
     if kv16 != (dv.dtype == torch.bfloat16):
         raise _capi.CapdecError("attn_bwd: dk and dv must have the same dtype")
-    fn = lib().capdec_attn_bwd_dkv16 if kv16 else lib().capdec_attn_bwd
+    in16 = k.dtype == torch.bfloat16  # K / V themselves are bf16: then so are dK / dV
+    if in16 and not (kv16 and v.dtype == torch.bfloat16):
+        raise _capi.CapdecError("attn_bwd: bf16 k / v need bf16 dk / dv")
+    fn = lib().capdec_attn_bwd_kv16 if in16 else (lib().capdec_attn_bwd_dkv16 if kv16 else lib().capdec_attn_bwd)
+    # algorithmic bytes: read Q, O, dO (fp32), K, V; write dQ (fp32), dK, dV -- bf16 blocks count half
     with _Timed(f"attn_bwd_{'causal' if causal else 'cross'}_{Tq}x{Tk}", 10.0 * B * H * Tq * Tk * dh,
-                4.0 * B * D * (4 * Tq + (3 if kv16 else 4) * Tk)):
+                4.0 * B * D * (4 * Tq + ((2 if in16 else 3) if kv16 else 4) * Tk)):
         check(fn(ptr(q), q.stride(0), ptr(k), k.stride(0), ptr(v), v.stride(0), ptr(o), o.stride(0),
                                     ptr(do), do.stride(0), ptr(lse), ptr(delta), ptr(dq), dq.stride(0) if dq is not None else D,
                                     ptr(dk),

@@ -82,6 +82,11 @@ typedef struct capdec_epilogue {
     const int64_t* ce_targets;
     float ce_eps;
     float ce_grad_scale;
+    /* bf16 result: if c16 != NULL the epilogue's result is written there as bf16 (round to nearest even, row stride
+     * ldc16 in bf16 elements) INSTEAD of to C (which may then be NULL; ldc still strides pre / aux) -- for results whose
+     * only readers take bf16 (the cross-attention K | V block of the bf16 storage path: capdec_attn_fwd_kv16). */
+    void* c16;
+    int ldc16;
 } capdec_epilogue;
 
 /* Split-K (chosen by the built-in cost model for small outputs with a long K, e.g. weight gradients) is combined
@@ -210,6 +215,17 @@ int capdec_attn_bwd(const void* q, int ldq, const void* k, int ldk, const void* 
                     const void* dout, int lddo, const void* lse, void* delta, void* dq, int lddq, void* dk, int lddk,
                     void* dv, int lddv, int B, int H, int Tq, int Tk, int dh, int causal, float scale, float drop_p,
                     uint64_t drop_seed, capdec_stream_t stream);
+/* Attention with K and V given as bf16 matrices (ldk / ldv in bf16 elements, multiples of 8; Tk > 1): they are
+ * widened to fp32 on their way into LDS and everything else is capdec_attn_fwd / capdec_attn_bwd_dkv16 (dK / dV come
+ * back as bf16 too).  For the bf16 storage path, whose K | V block exists only as bf16 (capdec_epilogue.c16): the
+ * attention kernels read K and V three times per layer and step, so this halves their largest stream. */
+int capdec_attn_fwd_kv16(const void* q, int ldq, const void* k16, int ldk, const void* v16, int ldv, void* o, int ldo,
+                         void* lse, int B, int H, int Tq, int Tk, int dh, int causal, float scale, float drop_p,
+                         uint64_t drop_seed, capdec_stream_t stream);
+int capdec_attn_bwd_kv16(const void* q, int ldq, const void* k16, int ldk, const void* v16, int ldv, const void* o, int ldo,
+                         const void* dout, int lddo, const void* lse, void* delta, void* dq, int lddq, void* dk16,
+                         int lddk, void* dv16, int lddv, int B, int H, int Tq, int Tk, int dh, int causal, float scale,
+                         float drop_p, uint64_t drop_seed, capdec_stream_t stream);
 /* capdec_attn_bwd with dK / dV written as bf16 matrices (lddk / lddv in bf16 elements, multiples of 8; Tk > 1): for
  * callers whose only consumers of dK / dV are CAPDEC_BF16S products (the cross-attention K/V projection's weight
  * and input gradients) -- saves the fp32 round trip and the cast pass of the step's largest gradient block.

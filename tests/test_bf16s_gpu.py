@@ -217,3 +217,42 @@ def test_attention_backward_writes_bf16_key_value_gradients(B, H, Tq, Tk, dh, ca
     assert torch.equal(dq, dq2)
     assert torch.equal(dk16, dk.to(torch.bfloat16)) and torch.equal(dv16, dv.to(torch.bfloat16))
     assert torch.all(buf[:, 2 * D:] == 7.0)  # nothing outside the two blocks is written
+
+
+def test_product_can_write_its_result_as_bf16():
+    """capdec_epilogue.c16: the same epilogue, the result stored as bf16 (RNE) in a padded block instead of fp32."""
+    ops = _ops()
+    g = torch.Generator().manual_seed(21)
+    M, N, K = 300, 200, 136
+    x, w, b = torch.randn(M, K, generator=g).to(DEV), (torch.randn(N, K, generator=g) / 4).to(DEV), torch.randn(N, generator=g).to(DEV)
+    for mode in ("bf16s", "fp32"):
+        with ops.compute_dtype(mode):
+            ref = ops.linear_fwd(x, w, b)
+            pitch = ops._bf16_pitch(N)
+            buf = torch.full((M, pitch), 3.0, dtype=torch.bfloat16, device=DEV)
+            out = ops.linear_fwd(x, w, b, out=buf[:, :N])
+        assert out.dtype == torch.bfloat16 and torch.equal(out, ref.to(torch.bfloat16)), mode
+        assert torch.all(buf[:, N:] == 3.0)
+
+
+@pytest.mark.parametrize("B,H,Tq,Tk,dh,causal", [(2, 8, 20, 196, 128, False), (3, 4, 12, 12, 32, True), (2, 2, 7, 45, 64, False)])
+def test_attention_reads_bf16_keys_and_values(B, H, Tq, Tk, dh, causal):
+    """capdec_attn_fwd_kv16 / capdec_attn_bwd_kv16: K and V given as bf16 are widened exactly, so the results must be
+    BIT-IDENTICAL to the fp32 entry points run on the widened values (dK / dV: their fp32 results rounded to bf16)."""
+    ops = _ops()
+    g = torch.Generator().manual_seed(B * 7 + Tk)
+    D = H * dh
+    q, do = torch.randn(B * Tq, D, generator=g).to(DEV), torch.randn(B * Tq, D, generator=g).to(DEV)
+    pitch = ops._bf16_pitch(2 * D)
+    kv16 = torch.randn(B * Tk, pitch, generator=g).to(DEV).to(torch.bfloat16)
+    k16, v16 = kv16[:, :D], kv16[:, D:2 * D]
+    kv32 = kv16.float()
+    k32, v32 = kv32[:, :D], kv32[:, D:2 * D]
+    o_ref, lse_ref = ops.attn_fwd(q, k32, v32, B, H, Tq, Tk, causal, 0.1, 5)
+    o, lse = ops.attn_fwd(q, k16, v16, B, H, Tq, Tk, causal, 0.1, 5)
+    assert torch.equal(o, o_ref) and torch.equal(lse, lse_ref)
+    dq_ref, dk_ref, dv_ref = ops.attn_bwd(q, k32, v32, o_ref, do, lse_ref, B, H, Tq, Tk, causal, 0.1, 5)
+    dbuf = torch.zeros((B * Tk, pitch), dtype=torch.bfloat16, device=DEV)
+    dq, dk, dv = ops.attn_bwd(q, k16, v16, o, do, lse, B, H, Tq, Tk, causal, 0.1, 5, dk=dbuf[:, :D], dv=dbuf[:, D:2 * D])
+    assert torch.equal(dq, dq_ref)
+    assert torch.equal(dk, dk_ref.to(torch.bfloat16)) and torch.equal(dv, dv_ref.to(torch.bfloat16))

@@ -34,6 +34,7 @@ SIGNATURES = {
     "capdec_gemm_plan_clear": (None, []),
     "capdec_gemm": (_i, [_i, _i, _i, _i, _i, _vp, _i, _vp, _i, _vp, _i, C.POINTER(Epilogue), _i, _vp, _sz, _vp]),
     "capdec_layernorm_bwd_workspace_bytes": (_sz, [_i, _i]),
+    "capdec_layernorm2_fwd": (_i, [_vp, _vp, _vp, _vp, _i, _vp, _vp, _vp, _i, _i, _f, _vp]),
     "capdec_layernorm_fwd": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _f, _i, _f, _u64, _vp]),
     "capdec_layernorm_bwd": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _f, _u64, _f, _u64,
                                   _vp, _sz, _vp]),

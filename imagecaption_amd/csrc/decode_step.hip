@@ -8,21 +8,7 @@
 #include <string.h>
 
 #include "common.h"
-
-namespace capdec {
-
-// out[r, :] = u[r / W, :] + x[r, :]  (the per-image constant cross-attention branch of a one-position memory)
-__global__ __launch_bounds__(256) void decode_add_rows_kernel(const float4* __restrict__ u, const float4* __restrict__ x,
-                                                               float4* __restrict__ out, int R, int d4, int W) {
-    const size_t total = (size_t)R * d4;
-    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (size_t)gridDim.x * 256) {
-        const int r = (int)(i / d4), c = (int)(i % d4);
-        const float4 a = u[(size_t)(r / W) * d4 + c], b = x[i];
-        out[i] = make_float4(a.x + b.x, a.y + b.y, a.z + b.z, a.w + b.w);
-    }
-}
-
-}  // namespace capdec
+#include "gemm_common.h"
 
 using namespace capdec;
 
@@ -81,28 +67,36 @@ extern "C" int capdec_decode_step(const capdec_decode_layer* layers, int L, void
         const float* w_in = (const float*)P.w_in;
         const float* b_in = (const float*)P.b_in;
         float* cache = (float*)P.cache;
-        STEP(linear(xf, d, w_in, b_in, d, q, d, nullptr, CAPDEC_ACT_NONE));
         // K | V of the new token go straight into the cache: position t of every row (row stride Tmax * 2d)
-        STEP(linear(xf, d, w_in + (size_t)d * d, b_in + d, 2 * d, cache + (size_t)t * 2 * d, Tmax * 2 * d, nullptr,
-                    CAPDEC_ACT_NONE));
-        STEP(capdec_decode_attn(q, d, cache, cache + d, 2 * d, a, d, anc, R, H, dh, Tmax, t, W, S, scale, stream));
-        STEP(linear(a, d, P.w_out, P.b_out, d, s1, d, xf, CAPDEC_ACT_NONE));
-        STEP(capdec_layernorm_fwd(s1, P.ln1_w, P.ln1_b, x1, nullptr, nullptr, R, d, eps, CAPDEC_ACT_NONE, 0.f, 0, stream));
-        if (S == 1) {
-            const size_t total = (size_t)R * (d / 4);
-            size_t blocks = (total + 255) / 256;
-            if (blocks > 4096) blocks = 4096;
-            hipLaunchKernelGGL(decode_add_rows_kernel, dim3((unsigned)blocks), dim3(256), 0, st, (const float4*)P.cross_out,
-                               (const float4*)x1, (float4*)s2, R, d / 4, W);
+        float* kv_t = cache + (size_t)t * 2 * d;
+        GemmParams qkv;
+        memset(&qkv, 0, sizeof(qkv));
+        qkv.A = xf; qkv.B = w_in; qkv.C = q; qkv.M = R; qkv.N = 3 * d; qkv.K = d; qkv.lda = d; qkv.ldb = d; qkv.ldc = d;
+        qkv.bias = b_in; qkv.drop = make_dropout(0.f, 0);
+        qkv.C2 = kv_t; qkv.ldc2 = Tmax * 2 * d; qkv.n_split = d;
+        if (gemm_skinny_ok(qkv, true, true, dtype)) {
+            // few rows: q and k | v as ONE product over the packed in-projection, its columns split between the query
+            // buffer and the cache (each output element is computed exactly as by the two separate products)
+            launch_gemm_skinny(qkv, st);
             STEP(check_launch("capdec_decode_step"));
         } else {
+            STEP(linear(xf, d, w_in, b_in, d, q, d, nullptr, CAPDEC_ACT_NONE));
+            STEP(linear(xf, d, w_in + (size_t)d * d, b_in + d, 2 * d, kv_t, Tmax * 2 * d, nullptr, CAPDEC_ACT_NONE));
+        }
+        STEP(capdec_decode_attn(q, d, cache, cache + d, 2 * d, a, d, anc, R, H, dh, Tmax, t, W, S, scale, stream));
+        STEP(linear(a, d, P.w_out, P.b_out, d, s1, d, xf, CAPDEC_ACT_NONE));
+        if (S == 1) {
+            // LayerNorm, + the per-image constant of the one-key cross-attention branch, LayerNorm: one launch
+            STEP(capdec_layernorm2_fwd(s1, P.ln1_w, P.ln1_b, P.cross_out, W, P.ln2_w, P.ln2_b, x2, R, d, eps, stream));
+        } else {
+            STEP(capdec_layernorm_fwd(s1, P.ln1_w, P.ln1_b, x1, nullptr, nullptr, R, d, eps, CAPDEC_ACT_NONE, 0.f, 0, stream));
             const float* wc = (const float*)P.wc_in;
             STEP(linear(x1, d, wc, P.bc_in, d, q, d, nullptr, CAPDEC_ACT_NONE));
             STEP(capdec_decode_attn(q, d, P.cross_kv, (const float*)P.cross_kv + d, 2 * d, a, d, nullptr, R, H, dh, Tmax, t, W,
                                     S, scale, stream));
             STEP(linear(a, d, P.wc_out, P.bc_out, d, s2, d, x1, CAPDEC_ACT_NONE));
+            STEP(capdec_layernorm_fwd(s2, P.ln2_w, P.ln2_b, x2, nullptr, nullptr, R, d, eps, CAPDEC_ACT_NONE, 0.f, 0, stream));
         }
-        STEP(capdec_layernorm_fwd(s2, P.ln2_w, P.ln2_b, x2, nullptr, nullptr, R, d, eps, CAPDEC_ACT_NONE, 0.f, 0, stream));
         STEP(linear(x2, d, P.w1, P.b1, dff, h, dff, nullptr, CAPDEC_ACT_GELU));
         {
             capdec_epilogue ep;

@@ -30,6 +30,10 @@ struct GemmParams {
     float ce_gs, ce_u, ce_w;  // grad scale, eps / V, 1 - eps
     __bf16* c16;            // if set: the result goes THERE as bf16 (row stride ldc16), not to C
     int ldc16;
+    // gemm_skinny.hip only (library-internal, capdec_decode_step): columns n >= n_split go to C2[m, n - n_split]
+    // (row stride ldc2) -- one product writes the query block and, through the cache's row stride, the K | V block
+    float* C2;
+    int ldc2, n_split;
 };
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));

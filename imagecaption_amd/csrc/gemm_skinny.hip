@@ -89,7 +89,8 @@ __global__ __launch_bounds__(512) void gemm_skinny_f32_kernel(GemmParams p) {
             else if (p.act == CAPDEC_ACT_GELU_BWD) v *= gelu_erf_grad(auxv[e]);
             if (p.drop.on()) v = p.drop.apply(v, (uint32_t)m * (uint32_t)p.N + (uint32_t)n);
             if (p.addend) v += addv[e];
-            p.C[o] = v;
+            if (p.C2 && n >= p.n_split) p.C2[(size_t)m * p.ldc2 + (n - p.n_split)] = v;
+            else p.C[o] = v;
         }
     }
 }

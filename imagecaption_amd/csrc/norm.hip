@@ -11,6 +11,19 @@ namespace capdec {
 
 constexpr int LN_MAX_BLOCKS = 512;
 
+// The forward LayerNorm arithmetic, spelled with explicit rounding intrinsics: ln_fwd_kernel and ln2_fwd_kernel (two
+// norms back to back in one launch) must give the same bits, and left to itself the compiler contracts the same
+// source expression differently in different surroundings (measured: 1-ulp row differences between the two kernels).
+__device__ __forceinline__ float ln_sum4(const float4& v) { return __fadd_rn(__fadd_rn(v.x, v.y), __fadd_rn(v.z, v.w)); }
+__device__ __forceinline__ float ln_sq4(const float4& v, float mean) {
+    const float a = __fsub_rn(v.x, mean), b = __fsub_rn(v.y, mean), c = __fsub_rn(v.z, mean), e = __fsub_rn(v.w, mean);
+    return __fadd_rn(__fmaf_rn(a, a, __fmul_rn(b, b)), __fmaf_rn(c, c, __fmul_rn(e, e)));
+}
+__device__ __forceinline__ float ln_out(float v, float mean, float rstd, float g, float b) {
+    return __fmaf_rn(__fmul_rn(__fsub_rn(v, mean), rstd), g, b);
+}
+__device__ __forceinline__ float ln_rstd(float sumsq, int d, float eps) { return rsqrtf(__fadd_rn(__fdiv_rn(sumsq, (float)d), eps)); }
+
 template <int NV>
 __global__ __launch_bounds__(256) void ln_fwd_kernel(const float* __restrict__ x, const float* __restrict__ gamma,
                                                       const float* __restrict__ beta, float* __restrict__ y,
@@ -27,19 +40,16 @@ __global__ __launch_bounds__(256) void ln_fwd_kernel(const float* __restrict__ x
     for (int i = 0; i < NV; ++i) {
         const int q = lane + 64 * i;
         v[i] = q < nq ? xr[q] : make_float4(0.f, 0.f, 0.f, 0.f);
-        s += (v[i].x + v[i].y) + (v[i].z + v[i].w);
+        s = __fadd_rn(s, ln_sum4(v[i]));
     }
-    const float mean = wave_sum(s) / (float)d;
+    const float mean = __fdiv_rn(wave_sum(s), (float)d);
     float ss = 0.f;
 #pragma unroll
     for (int i = 0; i < NV; ++i) {
         const int q = lane + 64 * i;
-        if (q < nq) {
-            const float a = v[i].x - mean, b = v[i].y - mean, c = v[i].z - mean, e = v[i].w - mean;
-            ss += (a * a + b * b) + (c * c + e * e);
-        }
+        if (q < nq) ss = __fadd_rn(ss, ln_sq4(v[i], mean));
     }
-    const float rstd = rsqrtf(wave_sum(ss) / (float)d + eps);
+    const float rstd = ln_rstd(wave_sum(ss), d, eps);
     if (lane == 0) {
         if (mean_out) mean_out[row] = mean;
         if (rstd_out) rstd_out[row] = rstd;
@@ -52,14 +62,69 @@ __global__ __launch_bounds__(256) void ln_fwd_kernel(const float* __restrict__ x
         const int q = lane + 64 * i;
         if (q < nq) {
             const float4 g = g4[q], b = b4[q];
-            float o[4] = {(v[i].x - mean) * rstd * g.x + b.x, (v[i].y - mean) * rstd * g.y + b.y,
-                          (v[i].z - mean) * rstd * g.z + b.z, (v[i].w - mean) * rstd * g.w + b.w};
+            float o[4] = {ln_out(v[i].x, mean, rstd, g.x, b.x), ln_out(v[i].y, mean, rstd, g.y, b.y),
+                          ln_out(v[i].z, mean, rstd, g.z, b.z), ln_out(v[i].w, mean, rstd, g.w, b.w)};
 #pragma unroll
             for (int j = 0; j < 4; ++j) {
                 if (act == CAPDEC_ACT_GELU) o[j] = gelu_erf(o[j]);
                 if (drop.on()) o[j] = drop.apply(o[j], (uint32_t)row * (uint32_t)d + (uint32_t)(q * 4 + j));
             }
             yr[q] = make_float4(o[0], o[1], o[2], o[3]);
+        }
+    }
+}
+
+// y = LN2(add[row / W] + LN1(x)): the two LayerNorms around the cross-attention branch of a decode step when the
+// memory is one position (the branch is then a per-image constant, decode.py).  One wave per row, the row stays in
+// registers between the two norms; each norm is ln_fwd_kernel's arithmetic, expression for expression, so the
+// result equals LN1 -> add -> LN2 issued as three launches bit for bit (tests/test_decode_gpu.py).
+template <int NV>
+__global__ __launch_bounds__(256) void ln2_fwd_kernel(const float* __restrict__ x, const float* __restrict__ gamma1,
+                                                       const float* __restrict__ beta1, const float* __restrict__ add, int W,
+                                                       const float* __restrict__ gamma2, const float* __restrict__ beta2,
+                                                       float* __restrict__ y, int M, int d, float eps) {
+    const int lane = threadIdx.x & 63;
+    const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (row >= M) return;
+    const int nq = d >> 2;
+    const float4* xr = reinterpret_cast<const float4*>(x + (size_t)row * d);
+    const float4* ar = reinterpret_cast<const float4*>(add + (size_t)(row / W) * d);
+    float4 v[NV];
+#pragma unroll
+    for (int i = 0; i < NV; ++i) {
+        const int q = lane + 64 * i;
+        v[i] = q < nq ? xr[q] : make_float4(0.f, 0.f, 0.f, 0.f);
+    }
+#pragma unroll
+    for (int pass = 0; pass < 2; ++pass) {
+        float s = 0.f;
+#pragma unroll
+        for (int i = 0; i < NV; ++i) s = __fadd_rn(s, ln_sum4(v[i]));
+        const float mean = __fdiv_rn(wave_sum(s), (float)d);
+        float ss = 0.f;
+#pragma unroll
+        for (int i = 0; i < NV; ++i) {
+            const int q = lane + 64 * i;
+            if (q < nq) ss = __fadd_rn(ss, ln_sq4(v[i], mean));
+        }
+        const float rstd = ln_rstd(wave_sum(ss), d, eps);
+        const float4* g4 = reinterpret_cast<const float4*>(pass ? gamma2 : gamma1);
+        const float4* b4 = reinterpret_cast<const float4*>(pass ? beta2 : beta1);
+#pragma unroll
+        for (int i = 0; i < NV; ++i) {
+            const int q = lane + 64 * i;
+            if (q < nq) {
+                const float4 g = g4[q], b = b4[q];
+                float4 o = make_float4(ln_out(v[i].x, mean, rstd, g.x, b.x), ln_out(v[i].y, mean, rstd, g.y, b.y),
+                                       ln_out(v[i].z, mean, rstd, g.z, b.z), ln_out(v[i].w, mean, rstd, g.w, b.w));
+                if (pass == 0) {
+                    const float4 u = ar[q];
+                    o = make_float4(__fadd_rn(u.x, o.x), __fadd_rn(u.y, o.y), __fadd_rn(u.z, o.z), __fadd_rn(u.w, o.w));
+                    v[i] = o;
+                } else {
+                    reinterpret_cast<float4*>(y + (size_t)row * d)[q] = o;
+                }
+            }
         }
     }
 }
@@ -210,6 +275,24 @@ extern "C" size_t capdec_layernorm_bwd_workspace_bytes(int M, int d) {
     else if ((NVREQ) <= 4) { CALL(4); }    \
     else if ((NVREQ) <= 8) { CALL(8); }    \
     else { CALL(16); }
+
+extern "C" int capdec_layernorm2_fwd(const void* x, const void* gamma1, const void* beta1, const void* add, int W,
+                                     const void* gamma2, const void* beta2, void* y, int M, int d, float eps,
+                                     capdec_stream_t stream) {
+    CAPDEC_REQUIRE(x && gamma1 && beta1 && add && gamma2 && beta2 && y, "capdec_layernorm2_fwd: null pointer");
+    CAPDEC_REQUIRE(M > 0 && W > 0 && d > 0 && d % 4 == 0 && d <= 4096, "capdec_layernorm2_fwd: bad shape M=%d W=%d d=%d", M, W, d);
+    CAPDEC_REQUIRE(aligned16(x) && aligned16(y) && aligned16(add) && aligned16(gamma1) && aligned16(beta1) && aligned16(gamma2) &&
+                       aligned16(beta2), "capdec_layernorm2_fwd: unaligned");
+    const int nv = (d + 255) / 256;
+    hipStream_t st = (hipStream_t)stream;
+#define CALL(NV)                                                                                                        \
+    hipLaunchKernelGGL((ln2_fwd_kernel<NV>), dim3((M + 3) / 4), dim3(256), 0, st, (const float*)x, (const float*)gamma1, \
+                       (const float*)beta1, (const float*)add, W, (const float*)gamma2, (const float*)beta2, (float*)y, M, \
+                       d, eps)
+    LN_DISPATCH(nv, CALL)
+#undef CALL
+    return check_launch("capdec_layernorm2_fwd");
+}
 
 extern "C" int capdec_layernorm_fwd(const void* x, const void* gamma, const void* beta, void* y, void* mean, void* rstd,
                                     int M, int d, float eps, int act, float drop_p, uint64_t drop_seed,

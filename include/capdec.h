@@ -140,6 +140,11 @@ int capdec_ce_dlogits_bf16(const void* logits, int ldl, const void* lse, const i
 size_t capdec_layernorm_bwd_workspace_bytes(int M, int d);
 int capdec_layernorm_fwd(const void* x, const void* gamma, const void* beta, void* y, void* mean, void* rstd,
                          int M, int d, float eps, int act, float drop_p, uint64_t drop_seed, capdec_stream_t stream);
+/* y = LN(gamma2, beta2)( add[row / W, :] + LN(gamma1, beta1)(x) ) in one launch: the two norms around a cross-attention
+ * branch whose output is a per-image constant (memory of one position, decode steps; capdec_decode_step uses it).
+ * Bit-identical to capdec_layernorm_fwd, a broadcast add and capdec_layernorm_fwd issued one after the other. */
+int capdec_layernorm2_fwd(const void* x, const void* gamma1, const void* beta1, const void* add, int W, const void* gamma2,
+                          const void* beta2, void* y, int M, int d, float eps, capdec_stream_t stream);
 int capdec_layernorm_bwd(const void* dy, const void* x, const void* gamma, const void* beta, const void* mean,
                          const void* rstd, void* dx, void* dx_drop, void* dgamma, void* dbeta, int M, int d,
                          int act, float drop_p, uint64_t drop_seed, float drop2_p, uint64_t drop2_seed,

@@ -654,3 +654,20 @@ def test_skinny_decode_product_with_epilogue_and_strided_output(M, N, K):
     finally:
         l.capdec_gemm_tune(0, 0, 0, 0)
     assert relerr(out, tiled) < 2e-6 * math.sqrt(K)
+
+
+@pytest.mark.parametrize("M,W,d", [(32, 1, 512), (30, 3, 512), (7, 1, 64), (64, 2, 1024)])
+def test_double_layernorm_with_broadcast_add_is_bit_identical_to_three_launches(M, W, d):
+    """capdec_layernorm2_fwd (decode steps with a one-position memory): LN -> + per-image constant -> LN in one launch."""
+    ops = _ops()
+    from imagecaption_amd._capi import lib, check, ptr, stream
+    g = torch.Generator().manual_seed(M + d)
+    x = torch.randn(M, d, generator=g).to(DEV)
+    u = torch.randn(M // W, d, generator=g).to(DEV)
+    g1, b1, g2, b2 = (torch.randn(d, generator=g).to(DEV) for _ in range(4))
+    x1, _, _ = ops.layernorm_fwd(x, g1, b1, save_stats=False)
+    want, _, _ = ops.layernorm_fwd(u.repeat_interleave(W, dim=0) + x1, g2, b2, save_stats=False)
+    y = torch.empty_like(x)
+    check(lib().capdec_layernorm2_fwd(ptr(x), ptr(g1), ptr(b1), ptr(u), W, ptr(g2), ptr(b2), ptr(y), M, d, 1e-5, stream()),
+          "capdec_layernorm2_fwd")
+    assert torch.equal(y, want)

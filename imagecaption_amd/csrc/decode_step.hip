@@ -77,7 +77,7 @@ extern "C" int capdec_decode_step(const capdec_decode_layer* layers, int L, void
         if (gemm_skinny_ok(qkv, true, true, dtype)) {
             // few rows: q and k | v as ONE product over the packed in-projection, its columns split between the query
             // buffer and the cache (each output element is computed exactly as by the two separate products)
-            launch_gemm_skinny(qkv, st);
+            STEP(launch_gemm_skinny(qkv, gemm_workspace, gemm_workspace_bytes, st));
             STEP(check_launch("capdec_decode_step"));
         } else {
             STEP(linear(xf, d, w_in, b_in, d, q, d, nullptr, CAPDEC_ACT_NONE));

@@ -283,7 +283,8 @@ int launch_gemm_f32x3(const GemmParams& p, const GemmPlan& pl, bool AK, bool BKM
 GemmPlan plan_gemm_bf16s(int M, int N, int K, const GemmForce& force);
 void launch_gemm_bf16s(const GemmParams& p, const GemmPlan& pl, bool AKC, bool BKC, hipStream_t st);  // A, B: bf16
 bool gemm_skinny_ok(const GemmParams& p, bool AK, bool BKM, int dtype);  // few-row decode products (gemm_skinny.hip)
-void launch_gemm_skinny(const GemmParams& p, hipStream_t st);
+int launch_gemm_skinny(GemmParams p, void* workspace, size_t workspace_bytes, hipStream_t st);  // 0 or CAPDEC_ERR_WORKSPACE
+size_t gemm_skinny_workspace_bytes(int M, int N, int K);
 bool gemm_bf16s_dma_ok(const GemmParams& p, bool AKC, bool BKC);  // operands fit the LDS-DMA kernels (gemm_bf16s_dma.hip)
 
 }  // namespace capdec

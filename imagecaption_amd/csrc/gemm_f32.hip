@@ -411,7 +411,8 @@ extern "C" void capdec_gemm_plan_clear(void) {
 
 extern "C" size_t capdec_gemm_workspace_bytes(int M, int N, int K) {
     if (M <= 0 || N <= 0 || K <= 0) return 0;
-    size_t need = 0;  // the largest need over both transposes of either operand and the three compute types
+    size_t need = 0;  // the largest need over both transposes of either operand and the compute types
+    if (M <= 64 && K % 64 == 0 && K >= 128) need = gemm_skinny_workspace_bytes(M, N, K);  // few-row products (gemm_skinny.hip)
     for (int ta = 0; ta < 2; ++ta)
         for (int tb = 0; tb < 2; ++tb)
             for (int dtype : {CAPDEC_F32, CAPDEC_BF16, CAPDEC_F32X3, CAPDEC_BF16S}) {
@@ -477,7 +478,7 @@ extern "C" int capdec_gemm(int transA, int transB, int M, int N, int K, const vo
     // a few rows against a weight matrix (decode steps): the K-split-inside-the-workgroup kernel, unless a plan was
     // forced (tuning hook / measured plan) for this product
     if (gemm_skinny_ok(p, !transA, transB != 0, dtype) && !resolve_force(transA, transB, M, N, K, dtype).bm) {
-        launch_gemm_skinny(p, (hipStream_t)stream);
+        if (const int rc = launch_gemm_skinny(p, workspace, workspace_bytes, (hipStream_t)stream)) return rc;
         return check_launch("capdec_gemm");
     }
     GemmPlan pl = clamp_plan(plan_for(transA, transB, M, N, K, dtype), M, N, K);

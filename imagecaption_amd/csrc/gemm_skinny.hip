@@ -21,8 +21,11 @@ __global__ __launch_bounds__(512) void gemm_skinny_f32_kernel(GemmParams p) {
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int l31 = lane & 31, half = lane >> 5;
     const int n0 = blockIdx.x * 32, m0 = blockIdx.y * 32;
-    const int krun = p.K / (2 * SK_WAVES);                 // k values per lane (a multiple of 4: checked by the host)
-    const int kbeg = wave * (p.K / SK_WAVES) + half * krun;
+    // gridDim.z workgroups share one output block, each with its own K slice (long reductions: a lone workgroup would
+    // be bound by what ONE CU can pull in); combined below through the workspace, deterministically
+    const int S = gridDim.z, kslice = p.K / S;
+    const int krun = kslice / (2 * SK_WAVES);              // k values per lane (a multiple of 4: checked by the host)
+    const int kbeg = blockIdx.z * kslice + wave * (kslice / SK_WAVES) + half * krun;
     const bool arow = m0 + l31 < p.M, brow = n0 + l31 < p.N;
     const float4* ap = reinterpret_cast<const float4*>(p.A + (size_t)min(m0 + l31, p.M - 1) * p.lda + kbeg);
     const float4* bp = reinterpret_cast<const float4*>(p.B + (size_t)min(n0 + l31, p.N - 1) * p.ldb + kbeg);
@@ -75,13 +78,47 @@ __global__ __launch_bounds__(512) void gemm_skinny_f32_kernel(GemmParams p) {
     __syncthreads();
     // 1024 outputs, 512 threads: thread -> column tid & 31, rows (tid >> 5) and (tid >> 5) + 16
     const int n = en;
+    float vsum[2];
+#pragma unroll
+    for (int e = 0; e < 2; ++e) {
+        const int row = (tid >> 5) + 16 * e;
+        float v = 0.f;
+#pragma unroll
+        for (int w = 0; w < SK_WAVES; ++w) v += red[w][row][tid & 31];
+        vsum[e] = v;
+    }
+    if (S > 1) {
+        // the recipe of splitk_combine (gemm_common.h): write-through partials, drain, one ticket per workgroup; the
+        // last arriver acquires, sums ALL slices in slice order (rounding independent of arrival order) and goes on
+        const int tile = blockIdx.y * gridDim.x + blockIdx.x;
+        float* slab0 = p.ws + (size_t)tile * S * 1024;
+        float* mine = slab0 + (size_t)blockIdx.z * 1024;
+#pragma unroll
+        for (int e = 0; e < 2; ++e) __hip_atomic_store(&mine[e * 512 + tid], vsum[e], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();  // also: every thread is done reading `red`, whose first word now carries the ticket
+        int* flag = reinterpret_cast<int*>(&red[0][0][0]);
+        if (tid == 0) *flag = __hip_atomic_fetch_add(&p.counters[tile], 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        __syncthreads();
+        if (*flag != S - 1) return;
+        if (tid == 0) {
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            __hip_atomic_store(&p.counters[tile], 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+        __syncthreads();
+#pragma unroll
+        for (int e = 0; e < 2; ++e) {
+            float v = 0.f;
+            for (int z = 0; z < S; ++z) v += slab0[(size_t)z * 1024 + e * 512 + tid];
+            vsum[e] = v;
+        }
+    }
 #pragma unroll
     for (int e = 0; e < 2; ++e) {
         const int row = (tid >> 5) + 16 * e, m = m0 + row;
         if (m < p.M && n < p.N) {
-            float v = 0.f;
-#pragma unroll
-            for (int w = 0; w < SK_WAVES; ++w) v += red[w][row][tid & 31];
+            float v = vsum[e];
             v += bias;
             const size_t o = (size_t)m * p.ldc + n;
             if (p.pre) p.pre[o] = v;
@@ -102,8 +139,35 @@ bool gemm_skinny_ok(const GemmParams& p, bool AK, bool BKM, int dtype) {
            aligned16(p.A) && aligned16(p.B) && !p.colsum && !p.ce_part && !p.ce_lse && !p.c16;
 }
 
-void launch_gemm_skinny(const GemmParams& p, hipStream_t st) {
-    hipLaunchKernelGGL(gemm_skinny_f32_kernel, dim3(cdiv(p.N, 32), cdiv(p.M, 32)), dim3(512), 0, st, p);
+// K slices per output block: a function of K ALONE (512 of K per workgroup, at most 8 slices), so that a product's
+// bits do not depend on how many columns it was launched with (capdec_decode_step merges q and k | v into one launch)
+int gemm_skinny_slices(int K) {
+    int s = K / 512;
+    if (s > 8) s = 8;
+    while (s > 1 && (K % s || (K / s) % 64)) --s;
+    return s < 1 ? 1 : s;
+}
+
+size_t gemm_skinny_workspace_bytes(int M, int N, int K) {
+    const int s = gemm_skinny_slices(K);
+    if (s <= 1) return 0;
+    return GEMM_COUNTER_BYTES + (size_t)cdiv(N, 32) * cdiv(M, 32) * s * 1024 * sizeof(float);
+}
+
+int launch_gemm_skinny(GemmParams p, void* workspace, size_t workspace_bytes, hipStream_t st) {
+    const int s = gemm_skinny_slices(p.K);
+    if (s > 1) {
+        const size_t need = gemm_skinny_workspace_bytes(p.M, p.N, p.K);
+        if (!workspace || workspace_bytes < need || !aligned16(workspace) || cdiv(p.N, 32) * cdiv(p.M, 32) > GEMM_SPLITK_MAX_TILES) {
+            set_error("capdec_gemm: the few-row product needs %zu workspace bytes (16-byte aligned) for its K slices, got %zu",
+                      need, workspace_bytes);
+            return CAPDEC_ERR_WORKSPACE;
+        }
+        p.counters = (int*)workspace;
+        p.ws = (float*)((char*)workspace + GEMM_COUNTER_BYTES);
+    }
+    hipLaunchKernelGGL(gemm_skinny_f32_kernel, dim3(cdiv(p.N, 32), cdiv(p.M, 32), s), dim3(512), 0, st, p);
+    return CAPDEC_OK;
 }
 
 }  // namespace capdec

@@ -96,6 +96,9 @@ typedef struct capdec_epilogue {
  * CAPDEC_GEMM_TICKET_BYTES hold the tile tickets, which must be ZERO the first time a workspace is passed and are
  * left zero by every call (so: zero a workspace once when allocating it, give capdec_gemm a workspace no other
  * entry point writes to, and never share one workspace between GEMMs that may run concurrently on two streams). */
+/* Few-row products (M <= 64, x[M,K] W[N,K]^T, fp32: the decode steps) run on a kernel of their own
+ * (csrc/gemm_skinny.hip) that cuts reductions longer than 512 into K slices combined the same way; their workspace
+ * need is part of capdec_gemm_workspace_bytes as well. */
 #define CAPDEC_GEMM_TICKET_BYTES 16384
 size_t capdec_gemm_workspace_bytes(int M, int N, int K);
 /* Tuning hook (process-global, not thread-safe): force block tile bm x bn in {64,128}^2 (CAPDEC_BF16S: 64 x 64,

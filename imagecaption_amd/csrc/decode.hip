@@ -118,6 +118,81 @@ __global__ __launch_bounds__(256) void decode_attn_kernel(DecodeAttnParams p) {
     if (g == 0) *reinterpret_cast<float4*>(p.out + (size_t)r * p.ldo + h * DH + e4 * 4) = o4;
 }
 
+// Self attention over the cache for SMALL batches: one workgroup (four waves) per (row, head), the key passes dealt
+// round-robin to the waves (each keeps its own online-softmax state) and merged through LDS in wave order.  With a
+// few hundred (row, head) items the one-wave kernel above leaves most of the chip idle and walks ~t keys serially
+// (20-25 us per call at t ~ 100, a quarter of a small-batch decode step); this one makes a call four times shorter
+// in passes.  Deterministic; not bit-identical to the one-wave kernel (the merge reassociates the softmax sums),
+// which keeps serving large batches and the cross-attention (where the beams' bit-identity is tested).
+template <int DH>
+__global__ __launch_bounds__(256) void decode_self_attn_split_kernel(DecodeAttnParams p) {
+    constexpr int LPK = DH / 4, KPI = 64 / LPK, UNR = 4;
+    __shared__ float sm_m[4], sm_l[4];
+    __shared__ __attribute__((aligned(16))) float sm_acc[4][DH];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int item = blockIdx.x;
+    const int r = item / p.H, h = item % p.H;
+    const int g = lane / LPK, e4 = lane % LPK;
+    const int nkeys = p.t + 1;
+    const int npass = (nkeys + KPI - 1) / KPI;
+    const float4 q4 = scaled_q(p.q + (size_t)r * p.ldq + h * DH + e4 * 4, p.scale);
+    RowAttn st{-INFINITY, 0.f, make_float4(0.f, 0.f, 0.f, 0.f)};
+    for (int p0 = wave; p0 < npass; p0 += 4 * UNR) {  // this wave's passes: wave, wave + 4, wave + 8, ...
+        bool valid[UNR];
+        size_t row[UNR];
+#pragma unroll
+        for (int u = 0; u < UNR; ++u) {
+            const int j = (p0 + 4 * u) * KPI + g;
+            valid[u] = j < nkeys;
+            row[u] = 0;
+            if (valid[u]) {
+                const int slot = j == p.t ? r : p.anc[(size_t)r * p.Tmax + j];
+                row[u] = (size_t)slot * p.Tmax + j;
+            }
+        }
+        float4 k4[UNR], v4[UNR];
+#pragma unroll
+        for (int u = 0; u < UNR; ++u) {
+            k4[u] = make_float4(0.f, 0.f, 0.f, 0.f);
+            v4[u] = k4[u];
+            if (valid[u]) {
+                k4[u] = *reinterpret_cast<const float4*>(p.k + row[u] * p.ldkv + h * DH + e4 * 4);
+                v4[u] = *reinterpret_cast<const float4*>(p.v + row[u] * p.ldkv + h * DH + e4 * 4);
+            }
+        }
+#pragma unroll
+        for (int u = 0; u < UNR; ++u) {
+            if (p0 + 4 * u < npass) row_attn_update<LPK>(st, q4, k4[u], v4[u], valid[u]);
+        }
+    }
+    // fold the key groups of this wave (as row_attn_finish does, without the division), publish the wave's state
+#pragma unroll
+    for (int o = LPK; o < 64; o <<= 1) {
+        st.acc.x = __fadd_rn(st.acc.x, __shfl_xor(st.acc.x, o, 64));
+        st.acc.y = __fadd_rn(st.acc.y, __shfl_xor(st.acc.y, o, 64));
+        st.acc.z = __fadd_rn(st.acc.z, __shfl_xor(st.acc.z, o, 64));
+        st.acc.w = __fadd_rn(st.acc.w, __shfl_xor(st.acc.w, o, 64));
+    }
+    if (g == 0) *reinterpret_cast<float4*>(&sm_acc[wave][e4 * 4]) = st.acc;
+    if (lane == 0) { sm_m[wave] = st.m; sm_l[wave] = st.l; }
+    __syncthreads();
+    if (wave == 0 && g == 0) {
+        const float M = fmaxf(fmaxf(sm_m[0], sm_m[1]), fmaxf(sm_m[2], sm_m[3]));  // finite: wave 0 always holds key 0
+        float L = 0.f;
+        float4 a = make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
+        for (int w = 0; w < 4; ++w) {
+            const float f = __expf(__fsub_rn(sm_m[w], M));  // a wave without keys: exp(-inf) = 0
+            const float4 x = *reinterpret_cast<const float4*>(&sm_acc[w][e4 * 4]);
+            L = __fmaf_rn(sm_l[w], f, L);
+            a.x = __fmaf_rn(x.x, f, a.x); a.y = __fmaf_rn(x.y, f, a.y); a.z = __fmaf_rn(x.z, f, a.z); a.w = __fmaf_rn(x.w, f, a.w);
+        }
+        const float inv = __fdiv_rn(1.f, L);
+        *reinterpret_cast<float4*>(p.out + (size_t)r * p.ldo + h * DH + e4 * 4) =
+            make_float4(__fmul_rn(a.x, inv), __fmul_rn(a.y, inv), __fmul_rn(a.z, inv), __fmul_rn(a.w, inv));
+    }
+}
+
 // Cross attention for beams: the NB hypotheses of one image attend the SAME per-image K/V, so one
 // wave serves all NB rows of an (image, head) and reads each key / value once (the per-row kernel
 // above reads them NB times; L2 absorbs that, but the CU-side delivery rate is what bounds it).
@@ -223,6 +298,7 @@ __global__ __launch_bounds__(256) void greedy_select_kernel(const float* __restr
 // sum-exp and candidate passes run on that copy (the unstaged kernel reads the row three times);
 // both variants assign elements to threads identically, so their results are bit-identical.
 constexpr int MAXW = 8;
+constexpr int DECODE_SPLIT_MAX_ITEMS = 2048;  // (row, head) items up to which the split-key self-attention kernel is used
 // LW: length of the per-thread candidate list (>= W + 1); the insertion cost is what bounds this kernel
 template <bool STAGE, int LW>
 __global__ __launch_bounds__(256) void beam_select_kernel(const float* __restrict__ logits, int ldl,
@@ -466,6 +542,13 @@ extern "C" int capdec_decode_attn(const void* q, int ldq, const void* k, const v
         if (dh == 32) { CAPDEC_XW(32) } else if (dh == 64) { CAPDEC_XW(64) } else { CAPDEC_XW(128) }
 #undef CAPDEC_XW
 #undef CAPDEC_X
+        return check_launch("capdec_decode_attn");
+    }
+    if (anc && R * H <= DECODE_SPLIT_MAX_ITEMS && t >= 16) {  // small batch, long prefix: four waves per (row, head)
+        const dim3 gs(R * H);
+        if (dh == 32) hipLaunchKernelGGL(decode_self_attn_split_kernel<32>, gs, dim3(256), 0, st, p);
+        else if (dh == 64) hipLaunchKernelGGL(decode_self_attn_split_kernel<64>, gs, dim3(256), 0, st, p);
+        else hipLaunchKernelGGL(decode_self_attn_split_kernel<128>, gs, dim3(256), 0, st, p);
         return check_launch("capdec_decode_attn");
     }
     if (dh == 32) hipLaunchKernelGGL(decode_attn_kernel<32>, grid, dim3(256), 0, st, p);

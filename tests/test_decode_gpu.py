@@ -4,6 +4,7 @@ Token ids must be bit-exact (north_star).  fp32 reduction orders differ between 
 argmax / top-k near-tie could legitimately flip; the goldens record the minimum top-1/top-2 margin
 (>= 8e-4 here, four orders above the fp32 noise of these logits) so exact equality is a fair bar.
 """
+import math
 import os
 
 import numpy as np
@@ -344,3 +345,32 @@ def test_one_call_decode_step_is_bit_identical_to_the_op_by_op_path(S):
     (ia, sa), (ib, sb) = one.beam(feats, beam=3, max_len=12), ops_.beam(feats, beam=3, max_len=12)
     assert torch.equal(ia, ib) and torch.equal(sa, sb)
     assert torch.equal(one.sample(feats, max_len=40, seed=5), ops_.sample(feats, max_len=40, seed=5))
+
+
+@pytest.mark.parametrize("H,dh,t", [(2, 64, 50), (8, 64, 199), (2, 32, 17), (1, 128, 64)])
+def test_split_key_self_attention_for_small_batches_matches_the_one_wave_kernel(H, dh, t):
+    """capdec_decode_attn picks a four-waves-per-(row, head) kernel for small batches with a long prefix; the same
+    rows embedded in a large batch run on the one-wave kernel: equal up to the reassociated softmax sums."""
+    from imagecaption_amd._capi import lib, check, ptr, stream
+    g = torch.Generator().manual_seed(H * 100 + t)
+    d, Tmax, Rs, Rb = H * dh, t + 3, 4, 2048 // H + 8
+    scale = 1.0 / math.sqrt(dh)
+
+    def run(R):
+        q = torch.zeros(R, d, device=DEV)
+        cache = torch.zeros(R, Tmax, 2 * d, device=DEV)
+        anc = torch.zeros(R, Tmax, dtype=torch.int32, device=DEV)
+        gg = torch.Generator().manual_seed(7)
+        q[:Rs] = torch.randn(Rs, d, generator=gg).to(DEV)
+        cache[:Rs] = torch.randn(Rs, Tmax, 2 * d, generator=gg).to(DEV)
+        anc[:Rs] = torch.randint(0, Rs, (Rs, Tmax), generator=gg).to(torch.int32).to(DEV)
+        out = torch.empty(R, d, device=DEV)
+        c2 = cache.view(-1, 2 * d)
+        check(lib().capdec_decode_attn(ptr(q), d, ptr(c2), ptr(c2[:, d:]), 2 * d, ptr(out), d, ptr(anc), R, H, dh, Tmax, t, 1, 1,
+                                       scale, stream()), "capdec_decode_attn")
+        return out[:Rs].clone()
+
+    small, big = run(Rs), run(Rb)
+    assert torch.isfinite(small).all()
+    assert float((small - big).abs().max() / big.abs().max()) < 2e-6
+    assert torch.equal(small, run(Rs))  # deterministic

@@ -412,7 +412,7 @@ extern "C" void capdec_gemm_plan_clear(void) {
 extern "C" size_t capdec_gemm_workspace_bytes(int M, int N, int K) {
     if (M <= 0 || N <= 0 || K <= 0) return 0;
     size_t need = 0;  // the largest need over both transposes of either operand and the compute types
-    if (M <= 64 && K % 64 == 0 && K >= 128) need = gemm_skinny_workspace_bytes(M, N, K);  // few-row products (gemm_skinny.hip)
+    if (M <= 64 && K % 128 == 0 && K >= 128) need = gemm_skinny_workspace_bytes(M, N, K);  // few-row products (gemm_skinny.hip)
     for (int ta = 0; ta < 2; ++ta)
         for (int tb = 0; tb < 2; ++tb)
             for (int dtype : {CAPDEC_F32, CAPDEC_BF16, CAPDEC_F32X3, CAPDEC_BF16S}) {

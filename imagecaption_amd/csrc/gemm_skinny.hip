@@ -13,10 +13,11 @@
 
 namespace capdec {
 
-constexpr int SK_WAVES = 8;
-constexpr int SK_CHUNK = 8;  // float4 loads per operand in flight per lane (32 k values)
+constexpr int SK_WAVES = 16;
+constexpr int SK_NT = SK_WAVES * 64, SK_EPT = 1024 / SK_NT;  // threads; outputs per thread
+constexpr int SK_CHUNK = 4;  // float4 loads per operand in flight per lane (32 k values)
 
-__global__ __launch_bounds__(512) void gemm_skinny_f32_kernel(GemmParams p) {
+__global__ __launch_bounds__(SK_NT) void gemm_skinny_f32_kernel(GemmParams p) {
     __shared__ float red[SK_WAVES][32][33];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int l31 = lane & 31, half = lane >> 5;
@@ -33,10 +34,10 @@ __global__ __launch_bounds__(512) void gemm_skinny_f32_kernel(GemmParams p) {
     // reduction would cost this latency-bound kernel another microsecond or two)
     const int en = n0 + (tid & 31);
     const float bias = (p.bias && en < p.N) ? p.bias[en] : 0.f;
-    float addv[2], auxv[2];
+    float addv[SK_EPT], auxv[SK_EPT];
 #pragma unroll
-    for (int e = 0; e < 2; ++e) {
-        const int m = m0 + (tid >> 5) + 16 * e;
+    for (int e = 0; e < SK_EPT; ++e) {
+        const int m = m0 + (tid >> 5) + (SK_NT / 32) * e;
         const bool ok = m < p.M && en < p.N;
         addv[e] = (p.addend && ok) ? p.addend[(size_t)m * p.ld_addend + en] : 0.f;
         auxv[e] = (p.act == CAPDEC_ACT_GELU_BWD && ok) ? p.aux[(size_t)m * p.ldc + en] : 0.f;
@@ -78,10 +79,10 @@ __global__ __launch_bounds__(512) void gemm_skinny_f32_kernel(GemmParams p) {
     __syncthreads();
     // 1024 outputs, 512 threads: thread -> column tid & 31, rows (tid >> 5) and (tid >> 5) + 16
     const int n = en;
-    float vsum[2];
+    float vsum[SK_EPT];
 #pragma unroll
-    for (int e = 0; e < 2; ++e) {
-        const int row = (tid >> 5) + 16 * e;
+    for (int e = 0; e < SK_EPT; ++e) {
+        const int row = (tid >> 5) + (SK_NT / 32) * e;
         float v = 0.f;
 #pragma unroll
         for (int w = 0; w < SK_WAVES; ++w) v += red[w][row][tid & 31];
@@ -94,7 +95,7 @@ __global__ __launch_bounds__(512) void gemm_skinny_f32_kernel(GemmParams p) {
         float* slab0 = p.ws + (size_t)tile * S * 1024;
         float* mine = slab0 + (size_t)blockIdx.z * 1024;
 #pragma unroll
-        for (int e = 0; e < 2; ++e) __hip_atomic_store(&mine[e * 512 + tid], vsum[e], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        for (int e = 0; e < SK_EPT; ++e) __hip_atomic_store(&mine[e * SK_NT + tid], vsum[e], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __syncthreads();  // also: every thread is done reading `red`, whose first word now carries the ticket
         int* flag = reinterpret_cast<int*>(&red[0][0][0]);
@@ -108,15 +109,15 @@ __global__ __launch_bounds__(512) void gemm_skinny_f32_kernel(GemmParams p) {
         }
         __syncthreads();
 #pragma unroll
-        for (int e = 0; e < 2; ++e) {
+        for (int e = 0; e < SK_EPT; ++e) {
             float v = 0.f;
-            for (int z = 0; z < S; ++z) v += slab0[(size_t)z * 1024 + e * 512 + tid];
+            for (int z = 0; z < S; ++z) v += slab0[(size_t)z * 1024 + e * SK_NT + tid];
             vsum[e] = v;
         }
     }
 #pragma unroll
-    for (int e = 0; e < 2; ++e) {
-        const int row = (tid >> 5) + 16 * e, m = m0 + row;
+    for (int e = 0; e < SK_EPT; ++e) {
+        const int row = (tid >> 5) + (SK_NT / 32) * e, m = m0 + row;
         if (m < p.M && n < p.N) {
             float v = vsum[e];
             v += bias;
@@ -135,7 +136,7 @@ __global__ __launch_bounds__(512) void gemm_skinny_f32_kernel(GemmParams p) {
 // x[M, K] * W[N, K]^T with few rows: exact fp32, K a multiple of 64 (8 waves x 2 lane halves x one float4),
 // 16-byte aligned operands with leading dimensions that are multiples of 4; no bias-gradient sums / CE partials
 bool gemm_skinny_ok(const GemmParams& p, bool AK, bool BKM, int dtype) {
-    return dtype == CAPDEC_F32 && AK && BKM && p.M <= 64 && p.K % 64 == 0 && p.K >= 128 && p.lda % 4 == 0 && p.ldb % 4 == 0 &&
+    return dtype == CAPDEC_F32 && AK && BKM && p.M <= 64 && p.K % (8 * SK_WAVES) == 0 && p.K >= 128 && p.lda % 4 == 0 && p.ldb % 4 == 0 &&
            aligned16(p.A) && aligned16(p.B) && !p.colsum && !p.ce_part && !p.ce_lse && !p.c16;
 }
 
@@ -144,7 +145,7 @@ bool gemm_skinny_ok(const GemmParams& p, bool AK, bool BKM, int dtype) {
 int gemm_skinny_slices(int K) {
     int s = K / 512;
     if (s > 8) s = 8;
-    while (s > 1 && (K % s || (K / s) % 64)) --s;
+    while (s > 1 && (K % s || (K / s) % (8 * SK_WAVES))) --s;
     return s < 1 ? 1 : s;
 }
 
@@ -166,7 +167,7 @@ int launch_gemm_skinny(GemmParams p, void* workspace, size_t workspace_bytes, hi
         p.counters = (int*)workspace;
         p.ws = (float*)((char*)workspace + GEMM_COUNTER_BYTES);
     }
-    hipLaunchKernelGGL(gemm_skinny_f32_kernel, dim3(cdiv(p.N, 32), cdiv(p.M, 32), s), dim3(512), 0, st, p);
+    hipLaunchKernelGGL(gemm_skinny_f32_kernel, dim3(cdiv(p.N, 32), cdiv(p.M, 32), s), dim3(SK_NT), 0, st, p);
     return CAPDEC_OK;
 }
 

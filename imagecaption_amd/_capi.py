@@ -57,6 +57,9 @@ SIGNATURES = {
                                   _i, _i, _i, _i, _i, _i, _f, _f, _u64, _vp]),
     "capdec_attn_bwd_dkv16": (_i, [_vp, _i, _vp, _i, _vp, _i, _vp, _i, _vp, _i, _vp, _vp, _vp, _i, _vp, _i, _vp, _i,
                                    _i, _i, _i, _i, _i, _i, _f, _f, _u64, _vp]),
+    "capdec_attn_fwd_bf16": (_i, [_vp, _i, _vp, _i, _vp, _i, _vp, _i, _vp, _i, _i, _i, _i, _i, _i, _f, _f, _u64, _vp]),
+    "capdec_attn_bwd_bf16": (_i, [_vp, _i, _vp, _i, _vp, _i, _vp, _i, _vp, _i, _vp, _vp, _vp, _i, _vp, _i, _vp, _i,
+                                  _i, _i, _i, _i, _i, _i, _f, _f, _u64, _vp]),
     "capdec_softmax_ce": (_i, [_vp, _i, _vp, _vp, _vp, _i, _i, _i, _f, _f, _vp]),
     "capdec_gemm_ce_tiles": (_i, [_i, _i, _i, _i]),
     "capdec_ce_finalize": (_i, [_vp, _i, _vp, _i, _vp, _vp, _vp, _i, _i, _f, _vp]),

@@ -16,10 +16,9 @@
 // Per-query scalars (softmax rescale, 1/l, lse, delta) reach the register-row layout through a
 // 32-float LDS line read back as four float4.
 #include "common.h"
+#include "attention_common.h"
 
 namespace capdec {
-
-typedef float f32x16 __attribute__((ext_vector_type(16)));
 
 struct AttnParams {
     const float* q; const float* k; const float* v; const float* o; const float* dout;
@@ -31,38 +30,6 @@ struct AttnParams {
     float scale;
     Dropout drop;
 };
-
-__device__ __forceinline__ int row_of(int r, int half) { return (r & 3) + 8 * (r >> 2) + 4 * half; }
-
-// Workgroup -> (batch*head, tile).  One workgroup reads 256-byte head slices out of rows that hold all H heads side
-// by side; which XCD (and so which L2) serves a workgroup is blockIdx % 8 (round-robin dispatch).  With the natural
-// order, head h of every image lands on XCD h % 8 and each L2 / memory channel sees nothing but isolated 256-byte
-// pieces.  Here each XCD gets a CONTIGUOUS run of (b, h) items in its own dispatch order, so the H heads of one
-// image run on one XCD at about the same time and its L2 is asked for whole rows (speed only, never correctness).
-// Causal launches keep their longest-tiles-first order inside that run.
-__device__ __forceinline__ void attn_item(int n_bh, int n_tiles, bool longest_first, int& bh, int& tile) {
-    const int nb = n_bh * n_tiles;
-    int blk = blockIdx.x;
-    if (n_bh % 8 == 0) {
-        const int xcd = blk & 7, idx = blk >> 3, per = n_bh >> 3;  // per-XCD share of the (b, h) items
-        if (longest_first) {
-            tile = idx / per;
-            bh = xcd * per + idx % per;
-        } else {
-            tile = idx % n_tiles;
-            bh = xcd * per + idx / n_tiles;
-        }
-        return;
-    }
-    (void)nb;
-    if (longest_first) {
-        tile = blk / n_bh;
-        bh = blk % n_bh;
-    } else {
-        tile = blk % n_tiles;
-        bh = blk / n_tiles;
-    }
-}
 
 // A 32 x DH tile moves global -> registers (coalesced: 16 consecutive lanes read one 256-B row
 // piece) -> LDS, in two separate steps so the global loads of the NEXT tile can be in flight

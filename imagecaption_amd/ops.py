@@ -540,7 +540,10 @@ def cross1_bwd(g, B, T, H, attn_p=0.0, attn_seed=0):
 
 def attn_fwd(q, k, v, B, H, Tq, Tk, causal, drop_p=0.0, seed=0, out=None, save_lse=True):
     """q [B*Tq, >=H*dh] / k, v [B*Tk, ...] row-strided 2-D views; returns o [B*Tq, H*dh], lse [B,H,Tq].
-    bf16 ``k`` / ``v`` (both, Tk > 1; views of a block a GEMM wrote as bf16) go through capdec_attn_fwd_kv16."""
+    bf16 ``k`` / ``v`` (both, Tk > 1; views of a block a GEMM wrote as bf16) go through capdec_attn_fwd_kv16.
+    bf16 ``q``: every matrix is bf16, ``o`` included (capdec_attn_fwd_bf16, head dims 64 / 128)."""
+    if q.dtype == torch.bfloat16:
+        return _attn_fwd_bf16(q, k, v, B, H, Tq, Tk, causal, drop_p, seed, out, save_lse)
     _mat(q, "attn.q")
     kv16 = k.dtype == torch.bfloat16
     if kv16:
@@ -561,9 +564,64 @@ def attn_fwd(q, k, v, B, H, Tq, Tk, causal, drop_p=0.0, seed=0, out=None, save_l
     return o, lse
 
 
+def bf16_matrix(rows, cols, device):
+    """An uninitialised bf16 [rows, cols] view with the row pitch of ops.cast_bf16 (for results that a kernel writes
+    as bf16: ``gemm(out=...)``, the bf16 attention).  The padding columns are NOT zeroed: fine whenever cols is a
+    multiple of 64 (the LDS-DMA products then never read them); zero them yourself otherwise."""
+    return torch.empty((rows, _bf16_pitch(cols)), dtype=torch.bfloat16, device=device)[:, :cols]
+
+
+def attn16_ok(H, D):
+    """The all-bf16 attention kernels (capdec_attn_*_bf16) cover head dims 64 and 128."""
+    return D % H == 0 and D // H in (64, 128)
+
+
+def _attn_fwd_bf16(q, k, v, B, H, Tq, Tk, causal, drop_p, seed, out, save_lse):
+    for t, n in ((q, "attn.q"), (k, "attn.k"), (v, "attn.v")):
+        if t.dtype != torch.bfloat16:
+            raise _capi.CapdecError(f"attn_fwd: bf16 q needs bf16 k and v, {n} is {t.dtype}")
+        _bf16_operand(t, n)
+    D = q.shape[1]
+    dh = D // H
+    o = bf16_matrix(B * Tq, D, q.device) if out is None else _bf16_operand(out, "attn.out")
+    lse = torch.empty((B, H, Tq), dtype=torch.float32, device=q.device) if save_lse else None
+    # algorithmic bytes: read Q, K, V, write O, all bf16
+    with _Timed(f"attn_fwd_{'causal' if causal else 'cross'}_{Tq}x{Tk}", 4.0 * B * H * Tq * Tk * dh,
+                2.0 * B * D * (2 * Tq + 2 * Tk)):
+        check(lib().capdec_attn_fwd_bf16(ptr(q), q.stride(0), ptr(k), k.stride(0), ptr(v), v.stride(0), ptr(o), o.stride(0),
+                                         ptr(lse), B, H, Tq, Tk, dh, int(causal), 1.0 / math.sqrt(dh), float(drop_p),
+                                         int(seed), stream()), "capdec_attn_fwd_bf16")
+    return o, lse
+
+
+def _attn_bwd_bf16(q, k, v, o, do, lse, B, H, Tq, Tk, causal, drop_p, seed, dq, dk, dv):
+    D = q.shape[1]
+    dh = D // H
+    dq = bf16_matrix(B * Tq, D, q.device) if dq is None else dq
+    dk = bf16_matrix(B * Tk, D, q.device) if dk is None else dk
+    dv = bf16_matrix(B * Tk, D, q.device) if dv is None else dv
+    for t, n in ((q, "q"), (k, "k"), (v, "v"), (o, "o"), (do, "do"), (dq, "dq"), (dk, "dk"), (dv, "dv")):
+        if t.dtype != torch.bfloat16:
+            raise _capi.CapdecError(f"attn_bwd: bf16 q needs every matrix bf16, {n} is {t.dtype}")
+        _bf16_operand(t, "attn_bwd." + n)
+    delta = torch.empty((B, H, Tq), dtype=torch.float32, device=q.device)
+    # algorithmic bytes: read Q, O, dO, K, V; write dQ, dK, dV, all bf16
+    with _Timed(f"attn_bwd_{'causal' if causal else 'cross'}_{Tq}x{Tk}", 10.0 * B * H * Tq * Tk * dh,
+                2.0 * B * D * (4 * Tq + 4 * Tk)):
+        check(lib().capdec_attn_bwd_bf16(ptr(q), q.stride(0), ptr(k), k.stride(0), ptr(v), v.stride(0), ptr(o), o.stride(0),
+                                         ptr(do), do.stride(0), ptr(_req(lse, "attn_bwd.lse")), ptr(delta), ptr(dq),
+                                         dq.stride(0), ptr(dk), dk.stride(0), ptr(dv), dv.stride(0), B, H, Tq, Tk, dh,
+                                         int(causal), 1.0 / math.sqrt(dh), float(drop_p), int(seed), stream()),
+              "capdec_attn_bwd_bf16")
+    return dq, dk, dv
+
+
 def attn_bwd(q, k, v, o, do, lse, B, H, Tq, Tk, causal, drop_p=0.0, seed=0, dq=None, dk=None, dv=None, need_dq=True):
     """``need_dq=False`` is accepted for Tk == 1 only (dq is exactly zero there and is then not written).
-    bf16 ``dk`` / ``dv`` (both, Tk > 1): the gradients are written as bf16 matrices (capdec_attn_bwd_dkv16)."""
+    bf16 ``dk`` / ``dv`` (both, Tk > 1): the gradients are written as bf16 matrices (capdec_attn_bwd_dkv16).
+    bf16 ``q``: every matrix is bf16 (capdec_attn_bwd_bf16)."""
+    if q.dtype == torch.bfloat16:
+        return _attn_bwd_bf16(q, k, v, o, do, lse, B, H, Tq, Tk, causal, drop_p, seed, dq, dk, dv)
     D = q.shape[1]
     dh = D // H
     _mat(do, "attn_bwd.do")

@@ -242,6 +242,20 @@ int capdec_attn_bwd_dkv16(const void* q, int ldq, const void* k, int ldk, const 
                           const void* dout, int lddo, const void* lse, void* delta, void* dq, int lddq, void* dk16,
                           int lddk, void* dv16, int lddv, int B, int H, int Tq, int Tk, int dh, int causal, float scale,
                           float drop_p, uint64_t drop_seed, capdec_stream_t stream);
+/* The same attention with EVERY matrix bf16 (q, k, v, o, dout, dq, dk, dv; all ld in bf16 elements, multiples of 8;
+ * each matrix under 2^31 elements; dh in {64, 128}; any Tk >= 1), lse / delta fp32: bf16 matrix products with fp32
+ * accumulation (v_mfma_f32_32x32x16_bf16), scores / softmax / statistics in fp32, probabilities rounded to bf16 for
+ * the context product.  For the CAPDEC_BF16S storage path, where the projections around attention read and write
+ * bf16 anyway (capdec_epilogue.c16): the walked K / V tiles stream global -> LDS by DMA, half the bytes of the fp32
+ * kernels and none of their conversions.  Same element indexing, causal rule, dropout element index (so the same
+ * masks for one seed) and replaced reference lines as capdec_attn_fwd / capdec_attn_bwd; lse may be NULL in fwd. */
+int capdec_attn_fwd_bf16(const void* q16, int ldq, const void* k16, int ldk, const void* v16, int ldv, void* o16, int ldo,
+                         void* lse, int B, int H, int Tq, int Tk, int dh, int causal, float scale, float drop_p,
+                         uint64_t drop_seed, capdec_stream_t stream);
+int capdec_attn_bwd_bf16(const void* q16, int ldq, const void* k16, int ldk, const void* v16, int ldv, const void* o16,
+                         int ldo, const void* do16, int lddo, const void* lse, void* delta, void* dq16, int lddq,
+                         void* dk16, int lddk, void* dv16, int lddv, int B, int H, int Tq, int Tk, int dh, int causal,
+                         float scale, float drop_p, uint64_t drop_seed, capdec_stream_t stream);
 
 /* ---- label-smoothed softmax cross-entropy, forward + backward in one pass -------------------------
  * Per row m of logits [M,V] (row stride ldl) with target y = targets[m] (int64):

@@ -72,13 +72,26 @@ def _single_key_fast(S, d, H):
     return S == 1 and d % 64 == 0 and H in (1, 2, 4, 8, 16)
 
 
+def _attn16(H, d):
+    return ops.COMPUTE_DTYPE == ops.BF16S and ops.attn16_ok(H, d)
+
+
+def _like16(t, rows, cols):
+    """bf16 result buffer when ``t`` (what forward saved) is bf16, else None (the product allocates fp32)."""
+    return ops.bf16_matrix(rows, cols, t.device) if t.dtype == torch.bfloat16 else None
+
+
 def layer_fwd(P, x, mem, B, T, S, H, causal, dp, l, save, kv=None):
     """x [B*T,d], mem [B*S,d] -> [B*T,d].  ``save`` (dict or None) receives what backward needs.
     ``kv``: this layer's cross-attention K/V projection of ``mem`` when the caller has already computed it
     (stack_fwd batches all layers' projections into one GEMM); a [B*S, 2d] row-strided view."""
     d = x.shape[1]
     p, sid = dp.p, 16 * l
-    qkv = ops.linear_fwd(x, P["self_attn.in_proj_weight"], P["self_attn.in_proj_bias"])
+    # bf16 storage: the projections around attention write bf16 and the all-bf16 attention kernels read / write it
+    # (q, k, v, the context and, in backward, dO, dq, dk, dv never exist as fp32; no cast passes around attention)
+    a16 = _attn16(H, d)
+    qkv = ops.linear_fwd(x, P["self_attn.in_proj_weight"], P["self_attn.in_proj_bias"],
+                         out=ops.bf16_matrix(x.shape[0], 3 * d, x.device) if a16 else None)
     a, lse1 = ops.attn_fwd(qkv[:, :d], qkv[:, d:2 * d], qkv[:, 2 * d:], B, H, T, T, causal, p, dp.seed(sid + S_SA_P),
                            save_lse=save is not None)
     s1 = ops.linear_fwd(a, P["self_attn.out_proj.weight"], P["self_attn.out_proj.bias"], drop_p=p,
@@ -86,7 +99,8 @@ def layer_fwd(P, x, mem, B, T, S, H, causal, dp, l, save, kv=None):
     x1, mean1, rstd1 = ops.layernorm_fwd(s1, P["norm1.weight"], P["norm1.bias"], save_stats=save is not None)
     wc, bc = P["multihead_attn.in_proj_weight"], P["multihead_attn.in_proj_bias"]
     if kv is None:
-        kv = ops.linear_fwd(mem, wc[d:], bc[d:])
+        kv = ops.linear_fwd(mem, wc[d:], bc[d:],
+                            out=ops.bf16_matrix(mem.shape[0], 2 * d, x.device) if a16 and S > 1 else None)
     q = c = lse2 = vblk = None
     if _single_key_fast(S, d, H):
         # ONE memory position (ref models.py:104): softmax over one key is 1 whatever the query (the query
@@ -98,7 +112,9 @@ def layer_fwd(P, x, mem, B, T, S, H, causal, dp, l, save, kv=None):
         s2 = ops.cross1_fwd(U, P["multihead_attn.out_proj.bias"], x1, B, T, H, p, dp.seed(sid + S_CA_P), p,
                             dp.seed(sid + S_CA_OUT))
     else:
-        q = x1 if S == 1 else ops.linear_fwd(x1, wc[:d], bc[:d])  # S == 1 with an odd geometry: generic kernels
+        # S == 1 with an odd geometry: generic kernels
+        q = x1 if S == 1 else ops.linear_fwd(x1, wc[:d], bc[:d],
+                                             out=ops.bf16_matrix(x.shape[0], d, x.device) if a16 else None)
         c, lse2 = ops.attn_fwd(q, kv[:, :d], kv[:, d:], B, H, T, S, False, p, dp.seed(sid + S_CA_P),
                                save_lse=save is not None and S != 1)
         s2 = ops.linear_fwd(c, P["multihead_attn.out_proj.weight"], P["multihead_attn.out_proj.bias"], drop_p=p,
@@ -153,11 +169,12 @@ def layer_bwd(P, G, sv, dx3, mem, dmem, B, T, S, H, causal, dp, l, dkv=None):
         gb[:d].zero_()
     else:
         ops.linear_wgrad(g2m, sv["c"], dw=G["multihead_attn.out_proj.weight"], db=G["multihead_attn.out_proj.bias"])
-        dc = ops.linear_dgrad(g2m, P["multihead_attn.out_proj.weight"])
+        dc = ops.linear_dgrad(g2m, P["multihead_attn.out_proj.weight"], out=_like16(sv["c"], g2m.shape[0], d))
         if not batched:
             dkv = torch.empty_like(kv)
         dq, _, _ = ops.attn_bwd(sv["q"], kv[:, :d], kv[:, d:], sv["c"], dc, sv["lse2"], B, H, T, S, False, p,
-                                dp.seed(sid + S_CA_P), dk=dkv[:, :d], dv=dkv[:, d:], need_dq=S != 1)
+                                dp.seed(sid + S_CA_P), dq=_like16(sv["q"], g2m.shape[0], d) if S != 1 else None,
+                                dk=dkv[:, :d], dv=dkv[:, d:], need_dq=S != 1)
         if S == 1:
             gw[:d].zero_()
             gb[:d].zero_()
@@ -172,9 +189,11 @@ def layer_bwd(P, G, sv, dx3, mem, dmem, B, T, S, H, causal, dp, l, dkv=None):
                                       dgamma=G["norm1.weight"], dbeta=G["norm1.bias"])
     g1m = g1m if tr else g1
     ops.linear_wgrad(g1m, sv["a"], dw=G["self_attn.out_proj.weight"], db=G["self_attn.out_proj.bias"])
-    da = ops.linear_dgrad(g1m, P["self_attn.out_proj.weight"])
     qkv = sv["qkv"]
-    dqkv = torch.empty_like(qkv)
+    da = ops.linear_dgrad(g1m, P["self_attn.out_proj.weight"], out=_like16(qkv, g1m.shape[0], d))
+    dqkv = _like16(qkv, qkv.shape[0], 3 * d)
+    if dqkv is None:
+        dqkv = torch.empty_like(qkv)
     ops.attn_bwd(qkv[:, :d], qkv[:, d:2 * d], qkv[:, 2 * d:], sv["a"], da, sv["lse1"], B, H, T, T, causal, p,
                  dp.seed(sid + S_SA_P), dq=dqkv[:, :d], dk=dqkv[:, d:2 * d], dv=dqkv[:, 2 * d:])
     ops.linear_wgrad(dqkv, sv["x"], dw=G["self_attn.in_proj_weight"], db=G["self_attn.in_proj_bias"])
@@ -195,10 +214,9 @@ def stack_fwd(layers, norm_w, norm_b, x, mem, B, T, S, H, causal, dp, save):
     if len(layers) > 1 and mem.shape[0] >= 1024:
         w_all = torch.cat([P["multihead_attn.in_proj_weight"][d:] for P in layers])
         b_all = torch.cat([P["multihead_attn.in_proj_bias"][d:] for P in layers])
-        # (bf16 storage: writing this block as bf16 for capdec_attn_*_kv16 was measured at C3 -- attention 4.2 -> 4.45 ms
-        # per step, step unchanged: the attention kernels are bound by their one-round structure, not by the K / V
-        # bytes -- so the block stays fp32; ops.linear_fwd(out=<bf16 view>) is how to do it)
-        kv_all = ops.linear_fwd(mem, w_all, b_all)
+        # bf16 storage: the block exists only as bf16 (capdec_epilogue.c16) and the all-bf16 attention kernels stream it
+        kv_all = ops.linear_fwd(mem, w_all, b_all, out=ops.bf16_matrix(mem.shape[0], w_all.shape[0], x.device)
+                                if _attn16(H, d) and S > 1 else None)
     for l, P in enumerate(layers):
         sv = {} if save is not None else None
         x = layer_fwd(P, x, mem, B, T, S, H, causal, dp, l, sv,

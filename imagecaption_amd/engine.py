@@ -76,6 +76,11 @@ def _attn16(H, d):
     return ops.COMPUTE_DTYPE == ops.BF16S and ops.attn16_ok(H, d)
 
 
+def _hidden16(rows, cols, device):
+    """bf16 storage with a 64-multiple width: a bf16-only result buffer (its padding is then never read); else None."""
+    return ops.bf16_matrix(rows, cols, device) if ops.COMPUTE_DTYPE == ops.BF16S and cols % 64 == 0 else None
+
+
 def _like16(t, rows, cols):
     """bf16 result buffer when ``t`` (what forward saved) is bf16, else None (the product allocates fp32)."""
     return ops.bf16_matrix(rows, cols, t.device) if t.dtype == torch.bfloat16 else None
@@ -122,8 +127,9 @@ def layer_fwd(P, x, mem, B, T, S, H, causal, dp, l, save, kv=None):
     x2, mean2, rstd2 = ops.layernorm_fwd(s2, P["norm2.weight"], P["norm2.bias"], save_stats=save is not None)
     u = torch.empty((x.shape[0], P["linear1.weight"].shape[0]), dtype=torch.float32, device=x.device) \
         if save is not None else None
+    # bf16 storage: the hidden activation is read by matrix products only -- it exists as bf16 alone
     h = ops.linear_fwd(x2, P["linear1.weight"], P["linear1.bias"], act=ACT_GELU, pre=u, drop_p=p,
-                       seed=dp.seed(sid + S_FFN_IN))
+                       seed=dp.seed(sid + S_FFN_IN), out=_hidden16(x.shape[0], P["linear1.weight"].shape[0], x.device))
     s3 = ops.linear_fwd(h, P["linear2.weight"], P["linear2.bias"], drop_p=p, seed=dp.seed(sid + S_FFN_OUT), addend=x2)
     x3, mean3, rstd3 = ops.layernorm_fwd(s3, P["norm3.weight"], P["norm3.bias"], save_stats=save is not None)
     if save is not None:
@@ -144,7 +150,8 @@ def layer_bwd(P, G, sv, dx3, mem, dmem, B, T, S, H, causal, dp, l, dkv=None):
                                       dgamma=G["norm3.weight"], dbeta=G["norm3.bias"])
     g3m = g3m if tr else g3
     ops.linear_wgrad(g3m, sv["h"], dw=G["linear2.weight"], db=G["linear2.bias"])
-    du = ops.linear_dgrad(g3m, P["linear2.weight"], gelu_pre=sv["u"], drop_p=p, seed=dp.seed(sid + S_FFN_IN))
+    du = ops.linear_dgrad(g3m, P["linear2.weight"], gelu_pre=sv["u"], drop_p=p, seed=dp.seed(sid + S_FFN_IN),
+                          out=_like16(sv["h"], *sv["h"].shape))
     ops.linear_wgrad(du, sv["x2"], dw=G["linear1.weight"], db=G["linear1.bias"])
     dx2 = ops.linear_dgrad(du, P["linear1.weight"], addend=g3)
     g2, g2m, _, _ = ops.layernorm_bwd(dx2, sv["s2"], P["norm2.weight"], P["norm2.bias"], sv["mean2"], sv["rstd2"],
@@ -290,7 +297,8 @@ def head_fwd(P, x, dp, save, logits_out=None, ce_partials=None):
     (label-smoothed cross-entropy fused into the product, ref train.py:41-50)."""
     u = torch.empty((x.shape[0], P["0.weight"].shape[0]), dtype=torch.float32, device=x.device) \
         if save is not None else None
-    h = ops.linear_fwd(x, P["0.weight"], P["0.bias"], act=ACT_GELU, pre=u, drop_p=dp.p, seed=dp.seed(S_HEAD))
+    h = ops.linear_fwd(x, P["0.weight"], P["0.bias"], act=ACT_GELU, pre=u, drop_p=dp.p, seed=dp.seed(S_HEAD),
+                       out=_hidden16(x.shape[0], P["0.weight"].shape[0], x.device))
     logits = ops.linear_fwd(h, P["3.weight"], P["3.bias"], out=logits_out, ce_partials=ce_partials)
     if save is not None:
         save.update(x=x, u=u, h=h)
@@ -301,6 +309,7 @@ def head_bwd(P, G, sv, dlogits, dp, ce=None):
     """``ce = (lse, targets, eps, grad_scale)``: ``dlogits`` is still the LOGITS block; both products read it through
     the cross-entropy gradient transform in their loaders (nothing is written back to the block)."""
     ops.linear_wgrad(dlogits, sv["h"], dw=G["3.weight"], db=G["3.bias"], ce=ce)
-    du = ops.linear_dgrad(dlogits, P["3.weight"], gelu_pre=sv["u"], drop_p=dp.p, seed=dp.seed(S_HEAD), ce=ce)
+    du = ops.linear_dgrad(dlogits, P["3.weight"], gelu_pre=sv["u"], drop_p=dp.p, seed=dp.seed(S_HEAD), ce=ce,
+                          out=_like16(sv["h"], *sv["h"].shape))
     ops.linear_wgrad(du, sv["x"], dw=G["0.weight"], db=G["0.bias"])
     return ops.linear_dgrad(du, P["0.weight"])

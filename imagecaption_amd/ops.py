@@ -342,9 +342,14 @@ def gemm(a, b, trans_a, trans_b, out=None, bias=None, addend=None, pre=None, aux
     ep = _capi.Epilogue()
     ep.bias, ep.addend, ep.pre, ep.aux, ep.colsum = ptr(bias), ptr(addend), ptr(pre), ptr(aux), ptr(colsum)
     ep.ld_addend = addend.stride(0) if addend is not None else 0
+    # pre / aux are fp32 [M, N] blocks addressed with the C row stride; with a bf16-only result there is no fp32 C
+    # and the ldc argument carries THEIR row stride instead (include/capdec.h, capdec_epilogue.c16)
+    ldc = out.stride(0)
+    if out16:
+        ldc = pre.stride(0) if pre is not None else (aux.stride(0) if aux is not None else N)
     for t, n in ((pre, "pre"), (aux, "aux")):
-        if t is not None and (t.stride(0) != out.stride(0) or tuple(t.shape) != (M, N)):
-            raise _capi.CapdecError(f"gemm: {n} must have the shape and row stride of out")
+        if t is not None and (t.stride(0) != ldc or tuple(t.shape) != (M, N)):
+            raise _capi.CapdecError(f"gemm: {n} must have the shape and row stride of out (of each other for a bf16 out)")
     if bias is not None and bias.numel() != N:
         raise _capi.CapdecError("gemm: bias must have N elements")
     if addend is not None and tuple(addend.shape) != (M, N):
@@ -353,8 +358,8 @@ def gemm(a, b, trans_a, trans_b, out=None, bias=None, addend=None, pre=None, aux
         raise _capi.CapdecError("gemm: colsum must have M elements")
     ep.act, ep.drop_p, ep.drop_seed = act, float(drop_p), int(seed) & 0xFFFFFFFFFFFFFFFF
     if out16:
-        if pre is not None or aux is not None or ce_partials is not None:
-            raise _capi.CapdecError("gemm: a bf16 result cannot be combined with pre / aux / ce_partials")
+        if ce_partials is not None:
+            raise _capi.CapdecError("gemm: a bf16 result cannot be combined with ce_partials")
         ep.c16, ep.ldc16 = ptr(out), out.stride(0)
     l = lib()
     if ce_partials is not None:
@@ -373,7 +378,7 @@ def gemm(a, b, trans_a, trans_b, out=None, bias=None, addend=None, pre=None, aux
     if need is None:
         need = _WS_NEED[(M, N, K)] = l.capdec_gemm_workspace_bytes(M, N, K)
     ws = _capi.workspace(need, a.device, "gemm:" + _WS_TAG, zero=True) if need else None
-    args = (int(trans_a), int(trans_b), M, N, K, ptr(a), a.stride(0), ptr(b), b.stride(0), None if out16 else ptr(out), out.stride(0),
+    args = (int(trans_a), int(trans_b), M, N, K, ptr(a), a.stride(0), ptr(b), b.stride(0), None if out16 else ptr(out), ldc,
             C.byref(ep), COMPUTE_DTYPE, ptr(ws), ws.numel() if ws is not None else 0, stream())
     if PROFILE is None:  # the common case: no per-launch events, no label formatting
         check(l.capdec_gemm(*args), "capdec_gemm")

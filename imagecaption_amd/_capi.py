@@ -40,6 +40,9 @@ SIGNATURES = {
                                   _vp, _sz, _vp]),
     "capdec_layernorm_bwd_dx": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _sz, _i, _i, _i, _f, _u64, _f, _u64, _vp]),
     "capdec_layernorm_bwd_dparams": (_i, [_vp, _vp, _vp, _i, _i, _vp]),
+    "capdec_layernorm_fwd_y16": (_i, [_vp, _vp, _vp, _vp, _vp, _i, _vp, _vp, _i, _i, _f, _i, _f, _u64, _vp]),
+    "capdec_layernorm_bwd_dx16": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _vp, _sz, _i, _i, _i, _f, _u64, _f, _u64,
+                                       _vp]),
     "capdec_layernorm_bwd_noalloc_max_bytes": (_sz, []),
     "capdec_layernorm_bwd_noalloc": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _f, _u64, _f,
                                           _u64, _vp]),

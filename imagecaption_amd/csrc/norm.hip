@@ -24,11 +24,25 @@ __device__ __forceinline__ float ln_out(float v, float mean, float rstd, float g
 }
 __device__ __forceinline__ float ln_rstd(float sumsq, int d, float eps) { return rsqrtf(__fadd_rn(__fdiv_rn(sumsq, (float)d), eps)); }
 
+// the bf16 copies some callers want next to (or instead of) an fp32 result: four values -> 8 bytes, and the zero padding
+// columns d .. ld16 - 1 of a row (capdec_cast_bf16's layout; d % 4 == 0 and ld16 % 8 == 0, so whole 8-byte groups)
+typedef __bf16 ln_bf16x4 __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ void store_bf16x4(__bf16* dst, const float* o) {
+    ln_bf16x4 v;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) v[j] = (__bf16)o[j];
+    *reinterpret_cast<ln_bf16x4*>(dst) = v;
+}
+__device__ __forceinline__ void zero_pad_bf16(__bf16* row, int d, int ld16, int lane) {
+    for (int c = d + lane * 4; c < ld16; c += 256) *reinterpret_cast<uint2*>(row + c) = make_uint2(0u, 0u);
+}
+
 template <int NV>
 __global__ __launch_bounds__(256) void ln_fwd_kernel(const float* __restrict__ x, const float* __restrict__ gamma,
                                                       const float* __restrict__ beta, float* __restrict__ y,
                                                       float* __restrict__ mean_out, float* __restrict__ rstd_out, int M,
-                                                      int d, float eps, int act, Dropout drop) {
+                                                      int d, float eps, int act, Dropout drop, __bf16* __restrict__ y16,
+                                                      int ld16) {
     const int lane = threadIdx.x & 63;
     const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
     if (row >= M) return;
@@ -70,8 +84,10 @@ __global__ __launch_bounds__(256) void ln_fwd_kernel(const float* __restrict__ x
                 if (drop.on()) o[j] = drop.apply(o[j], (uint32_t)row * (uint32_t)d + (uint32_t)(q * 4 + j));
             }
             yr[q] = make_float4(o[0], o[1], o[2], o[3]);
+            if (y16) store_bf16x4(y16 + (size_t)row * ld16 + q * 4, o);
         }
     }
+    if (y16) zero_pad_bf16(y16 + (size_t)row * ld16, d, ld16, lane);
 }
 
 // y = LN2(add[row / W] + LN1(x)): the two LayerNorms around the cross-attention branch of a decode step when the
@@ -135,7 +151,7 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(const float* __restrict__ d
                                                       const float* __restrict__ mean_in, const float* __restrict__ rstd_in,
                                                       float* __restrict__ dx, float* __restrict__ dx_drop,
                                                       float* __restrict__ part, int M, int d, int act, Dropout drop,
-                                                      Dropout drop2) {
+                                                      Dropout drop2, __bf16* __restrict__ dxd16, int ld16) {
     __shared__ float red[2][NV * 256];  // the four waves add their column partials into it one after the other
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int nq = d >> 2;
@@ -194,14 +210,16 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(const float* __restrict__ d
 #pragma unroll
                 for (int j = 0; j < 4; ++j) o[j] = rstd * (g[i][j] - c1 - xh[i][j] * c2);
                 dxr[q] = make_float4(o[0], o[1], o[2], o[3]);
-                if (dxd) {
+                if (dxd || dxd16) {
 #pragma unroll
                     for (int j = 0; j < 4; ++j)
                         o[j] = drop2.on() ? drop2.apply(o[j], (uint32_t)row * (uint32_t)d + (uint32_t)(q * 4 + j)) : o[j];
-                    dxd[q] = make_float4(o[0], o[1], o[2], o[3]);
+                    if (dxd) dxd[q] = make_float4(o[0], o[1], o[2], o[3]);
+                    if (dxd16) store_bf16x4(dxd16 + (size_t)row * ld16 + q * 4, o);
                 }
             }
         }
+        if (dxd16) zero_pad_bf16(dxd16 + (size_t)row * ld16, d, ld16, lane);
     }
     // block reduction of the per-wave partial column sums in wave order (fixed: reproducible), in ONE [2][d] LDS
     // image (4 KiB at d = 512; a per-wave image each cost 16 KiB and with it this kernel's place on CUs it shares
@@ -294,22 +312,38 @@ extern "C" int capdec_layernorm2_fwd(const void* x, const void* gamma1, const vo
     return check_launch("capdec_layernorm2_fwd");
 }
 
-extern "C" int capdec_layernorm_fwd(const void* x, const void* gamma, const void* beta, void* y, void* mean, void* rstd,
-                                    int M, int d, float eps, int act, float drop_p, uint64_t drop_seed,
-                                    capdec_stream_t stream) {
-    CAPDEC_REQUIRE(x && gamma && beta && y, "capdec_layernorm_fwd: null pointer");
-    CAPDEC_REQUIRE(M > 0 && d > 0 && d % 4 == 0 && d <= 4096, "capdec_layernorm_fwd: bad shape M=%d d=%d", M, d);
-    CAPDEC_REQUIRE(aligned16(x) && aligned16(y) && aligned16(gamma) && aligned16(beta), "capdec_layernorm_fwd: unaligned");
-    CAPDEC_REQUIRE((uint64_t)M * (uint64_t)d < (1ull << 32), "capdec_layernorm_fwd: M*d exceeds 2^32");
+static int ln_fwd_launch(const char* what, const void* x, const void* gamma, const void* beta, void* y, void* y16, int ldy16,
+                         void* mean, void* rstd, int M, int d, float eps, int act, float drop_p, uint64_t drop_seed,
+                         capdec_stream_t stream) {
+    CAPDEC_REQUIRE(x && gamma && beta && y, "%s: null pointer", what);
+    CAPDEC_REQUIRE(M > 0 && d > 0 && d % 4 == 0 && d <= 4096, "%s: bad shape M=%d d=%d", what, M, d);
+    CAPDEC_REQUIRE(aligned16(x) && aligned16(y) && aligned16(gamma) && aligned16(beta), "%s: unaligned", what);
+    CAPDEC_REQUIRE((uint64_t)M * (uint64_t)d < (1ull << 32), "%s: M*d exceeds 2^32", what);
     const Dropout dr = make_dropout(drop_p, drop_seed);
     const int nv = (d + 255) / 256;
     hipStream_t st = (hipStream_t)stream;
 #define CALL(NV)                                                                                                    \
     hipLaunchKernelGGL((ln_fwd_kernel<NV>), dim3((M + 3) / 4), dim3(256), 0, st, (const float*)x, (const float*)gamma, \
-                       (const float*)beta, (float*)y, (float*)mean, (float*)rstd, M, d, eps, act, dr)
+                       (const float*)beta, (float*)y, (float*)mean, (float*)rstd, M, d, eps, act, dr, (__bf16*)y16, ldy16)
     LN_DISPATCH(nv, CALL)
 #undef CALL
-    return check_launch("capdec_layernorm_fwd");
+    return check_launch(what);
+}
+
+extern "C" int capdec_layernorm_fwd(const void* x, const void* gamma, const void* beta, void* y, void* mean, void* rstd,
+                                    int M, int d, float eps, int act, float drop_p, uint64_t drop_seed,
+                                    capdec_stream_t stream) {
+    return ln_fwd_launch("capdec_layernorm_fwd", x, gamma, beta, y, nullptr, 0, mean, rstd, M, d, eps, act, drop_p, drop_seed,
+                         stream);
+}
+
+extern "C" int capdec_layernorm_fwd_y16(const void* x, const void* gamma, const void* beta, void* y, void* y16, int ldy16,
+                                        void* mean, void* rstd, int M, int d, float eps, int act, float drop_p,
+                                        uint64_t drop_seed, capdec_stream_t stream) {
+    CAPDEC_REQUIRE(y16 && aligned16(y16) && ldy16 % 8 == 0 && ldy16 >= d,
+                   "capdec_layernorm_fwd_y16: y16 must be a 16-byte aligned bf16 matrix with ldy16 %% 8 == 0, ldy16 >= d");
+    return ln_fwd_launch("capdec_layernorm_fwd_y16", x, gamma, beta, y, y16, ldy16, mean, rstd, M, d, eps, act, drop_p,
+                         drop_seed, stream);
 }
 
 // Shared launch plan of capdec_layernorm_bwd and capdec_layernorm_bwd_noalloc: `part` is the
@@ -325,7 +359,7 @@ static int ln_bwd_launch(const char* what, const void* dy, const void* x, const 
 #define CALL(NV)                                                                                                     \
     hipLaunchKernelGGL((ln_bwd_kernel<NV>), dim3(nblk), dim3(256), 0, st, (const float*)dy, (const float*)x,          \
                        (const float*)gamma, (const float*)beta, (const float*)mean, (const float*)rstd, (float*)dx,   \
-                       (float*)dx_drop, part, M, d, act, dr, dr2)
+                       (float*)dx_drop, part, M, d, act, dr, dr2, (__bf16*)nullptr, 0)
     if (nv <= 1) { CALL(1); } else if (nv <= 2) { CALL(2); } else if (nv <= 4) { CALL(4); } else { CALL(8); }
 #undef CALL
     int rc = check_launch(what);
@@ -364,11 +398,10 @@ extern "C" int capdec_layernorm_bwd(const void* dy, const void* x, const void* g
 // The two halves of capdec_layernorm_bwd as separate calls: dx (+ dx_drop) and the per-workgroup column partials
 // first, the parameter gradients from those partials later -- e.g. on another stream: dgamma / dbeta are weight
 // gradients, nothing on the backward critical path waits for them.
-extern "C" int capdec_layernorm_bwd_dx(const void* dy, const void* x, const void* gamma, const void* beta, const void* mean,
-                                       const void* rstd, void* dx, void* dx_drop, void* partials, size_t partials_bytes,
-                                       int M, int d, int act, float drop_p, uint64_t drop_seed, float drop2_p,
-                                       uint64_t drop2_seed, capdec_stream_t stream) {
-    const char* what = "capdec_layernorm_bwd_dx";
+static int ln_bwd_dx_launch(const char* what, const void* dy, const void* x, const void* gamma, const void* beta,
+                            const void* mean, const void* rstd, void* dx, void* dx_drop, void* dx_drop16, int lddd,
+                            void* partials, size_t partials_bytes, int M, int d, int act, float drop_p, uint64_t drop_seed,
+                            float drop2_p, uint64_t drop2_seed, capdec_stream_t stream) {
     float dummy;  // ln_bwd_check wants non-null parameter-gradient pointers; this call writes none
     if (int rc = ln_bwd_check(what, dy, x, gamma, beta, mean, rstd, dx, dx_drop, &dummy, &dummy, M, d)) return rc;
     const size_t need = (size_t)ln_blocks(M) * 2 * d * sizeof(float);
@@ -382,10 +415,28 @@ extern "C" int capdec_layernorm_bwd_dx(const void* dy, const void* x, const void
 #define CALL(NV)                                                                                                     \
     hipLaunchKernelGGL((ln_bwd_kernel<NV>), dim3(nblk), dim3(256), 0, st, (const float*)dy, (const float*)x,          \
                        (const float*)gamma, (const float*)beta, (const float*)mean, (const float*)rstd, (float*)dx,   \
-                       (float*)dx_drop, (float*)partials, M, d, act, dr, dr2)
+                       (float*)dx_drop, (float*)partials, M, d, act, dr, dr2, (__bf16*)dx_drop16, lddd)
     if (nv <= 1) { CALL(1); } else if (nv <= 2) { CALL(2); } else if (nv <= 4) { CALL(4); } else { CALL(8); }
 #undef CALL
     return check_launch(what);
+}
+
+extern "C" int capdec_layernorm_bwd_dx(const void* dy, const void* x, const void* gamma, const void* beta, const void* mean,
+                                       const void* rstd, void* dx, void* dx_drop, void* partials, size_t partials_bytes,
+                                       int M, int d, int act, float drop_p, uint64_t drop_seed, float drop2_p,
+                                       uint64_t drop2_seed, capdec_stream_t stream) {
+    return ln_bwd_dx_launch("capdec_layernorm_bwd_dx", dy, x, gamma, beta, mean, rstd, dx, dx_drop, nullptr, 0, partials,
+                            partials_bytes, M, d, act, drop_p, drop_seed, drop2_p, drop2_seed, stream);
+}
+
+extern "C" int capdec_layernorm_bwd_dx16(const void* dy, const void* x, const void* gamma, const void* beta,
+                                         const void* mean, const void* rstd, void* dx, void* dx_drop16, int lddd,
+                                         void* partials, size_t partials_bytes, int M, int d, int act, float drop_p,
+                                         uint64_t drop_seed, float drop2_p, uint64_t drop2_seed, capdec_stream_t stream) {
+    CAPDEC_REQUIRE(dx_drop16 && aligned16(dx_drop16) && lddd % 8 == 0 && lddd >= d,
+                   "capdec_layernorm_bwd_dx16: dx_drop16 must be a 16-byte aligned bf16 matrix with lddd %% 8 == 0, lddd >= d");
+    return ln_bwd_dx_launch("capdec_layernorm_bwd_dx16", dy, x, gamma, beta, mean, rstd, dx, nullptr, dx_drop16, lddd,
+                            partials, partials_bytes, M, d, act, drop_p, drop_seed, drop2_p, drop2_seed, stream);
 }
 
 extern "C" int capdec_layernorm_bwd_dparams(const void* partials, void* dgamma, void* dbeta, int M, int d,

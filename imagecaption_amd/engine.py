@@ -145,19 +145,23 @@ def layer_bwd(P, G, sv, dx3, mem, dmem, B, T, S, H, causal, dp, l, dkv=None):
     d = dx3.shape[1]
     p, sid = dp.p, 16 * l
     tr = p > 0.0
+    # bf16 storage: the gradients entering the branch dropouts are read by matrix products only -- the LayerNorm
+    # backward writes them as bf16 (with p == 0 that is the bf16 copy of dx) and nothing casts them
+    d16 = ops.COMPUTE_DTYPE == ops.BF16S
+    d16c = d16 and not _single_key_fast(S, d, H)  # the streaming single-key branch reads this one as fp32
     g3, g3m, _, _ = ops.layernorm_bwd(dx3, sv["s3"], P["norm3.weight"], P["norm3.bias"], sv["mean3"], sv["rstd3"],
-                                      drop2_p=p, seed2=dp.seed(sid + S_FFN_OUT), want_dx_drop=tr,
-                                      dgamma=G["norm3.weight"], dbeta=G["norm3.bias"])
-    g3m = g3m if tr else g3
+                                      drop2_p=p, seed2=dp.seed(sid + S_FFN_OUT), want_dx_drop=tr or d16,
+                                      dgamma=G["norm3.weight"], dbeta=G["norm3.bias"], dx_drop16=d16)
+    g3m = g3m if tr or d16 else g3
     ops.linear_wgrad(g3m, sv["h"], dw=G["linear2.weight"], db=G["linear2.bias"])
     du = ops.linear_dgrad(g3m, P["linear2.weight"], gelu_pre=sv["u"], drop_p=p, seed=dp.seed(sid + S_FFN_IN),
                           out=_like16(sv["h"], *sv["h"].shape))
     ops.linear_wgrad(du, sv["x2"], dw=G["linear1.weight"], db=G["linear1.bias"])
     dx2 = ops.linear_dgrad(du, P["linear1.weight"], addend=g3)
     g2, g2m, _, _ = ops.layernorm_bwd(dx2, sv["s2"], P["norm2.weight"], P["norm2.bias"], sv["mean2"], sv["rstd2"],
-                                      drop2_p=p, seed2=dp.seed(sid + S_CA_OUT), want_dx_drop=tr,
-                                      dgamma=G["norm2.weight"], dbeta=G["norm2.bias"])
-    g2m = g2m if tr else g2
+                                      drop2_p=p, seed2=dp.seed(sid + S_CA_OUT), want_dx_drop=tr or d16c,
+                                      dgamma=G["norm2.weight"], dbeta=G["norm2.bias"], dx_drop16=d16c)
+    g2m = g2m if tr or d16c else g2
     kv = sv["kv"]
     batched = dkv is not None
     wc = P["multihead_attn.in_proj_weight"]
@@ -192,9 +196,9 @@ def layer_bwd(P, G, sv, dx3, mem, dmem, B, T, S, H, causal, dp, l, dkv=None):
         dmem = ops.linear_dgrad(dkv, wc[d:], addend=dmem)
     dx1 = g2 if S == 1 else ops.linear_dgrad(dq, wc[:d], addend=g2)
     g1, g1m, _, _ = ops.layernorm_bwd(dx1, sv["s1"], P["norm1.weight"], P["norm1.bias"], sv["mean1"], sv["rstd1"],
-                                      drop2_p=p, seed2=dp.seed(sid + S_SA_OUT), want_dx_drop=tr,
-                                      dgamma=G["norm1.weight"], dbeta=G["norm1.bias"])
-    g1m = g1m if tr else g1
+                                      drop2_p=p, seed2=dp.seed(sid + S_SA_OUT), want_dx_drop=tr or d16,
+                                      dgamma=G["norm1.weight"], dbeta=G["norm1.bias"], dx_drop16=d16)
+    g1m = g1m if tr or d16 else g1
     ops.linear_wgrad(g1m, sv["a"], dw=G["self_attn.out_proj.weight"], db=G["self_attn.out_proj.bias"])
     qkv = sv["qkv"]
     da = ops.linear_dgrad(g1m, P["self_attn.out_proj.weight"], out=_like16(qkv, g1m.shape[0], d))
@@ -281,12 +285,16 @@ def proj_fwd(P, f, dp, save):
 
 
 def proj_bwd(P, G, sv, dmem, dp, want_df=False):
-    g5, _, _, _ = ops.layernorm_bwd(dmem, sv["h2"], P["5.weight"], P["5.bias"], sv["mean5"], sv["rstd5"],
-                                    dgamma=G["5.weight"], dbeta=G["5.bias"])
+    d16 = ops.COMPUTE_DTYPE == ops.BF16S  # both dx feed matrix products only: bf16 copies straight from the kernel
+    g5, g5c, _, _ = ops.layernorm_bwd(dmem, sv["h2"], P["5.weight"], P["5.bias"], sv["mean5"], sv["rstd5"],
+                                      dgamma=G["5.weight"], dbeta=G["5.bias"], want_dx_drop=d16, dx_drop16=d16)
+    g5 = g5c if d16 else g5
     ops.linear_wgrad(g5, sv["h1"], dw=G["4.weight"], db=G["4.bias"])
     dh1 = ops.linear_dgrad(g5, P["4.weight"])
-    g1, _, _, _ = ops.layernorm_bwd(dh1, sv["h0"], P["1.weight"], P["1.bias"], sv["mean1"], sv["rstd1"], act=ACT_GELU,
-                                    drop_p=dp.p, seed=dp.seed(S_PROJ), dgamma=G["1.weight"], dbeta=G["1.bias"])
+    g1, g1c, _, _ = ops.layernorm_bwd(dh1, sv["h0"], P["1.weight"], P["1.bias"], sv["mean1"], sv["rstd1"], act=ACT_GELU,
+                                      drop_p=dp.p, seed=dp.seed(S_PROJ), dgamma=G["1.weight"], dbeta=G["1.bias"],
+                                      want_dx_drop=d16, dx_drop16=d16)
+    g1 = g1c if d16 else g1
     ops.linear_wgrad(g1, sv["f"], dw=G["0.weight"], db=G["0.bias"])
     return ops.linear_dgrad(g1, P["0.weight"]) if want_df else None
 

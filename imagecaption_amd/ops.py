@@ -421,25 +421,49 @@ def layernorm_fwd(x, gamma, beta, eps=1e-5, act=ACT_NONE, drop_p=0.0, seed=0, sa
     y = torch.empty_like(x) if out is None else out
     mean = torch.empty(M, dtype=torch.float32, device=x.device) if save_stats else None
     rstd = torch.empty(M, dtype=torch.float32, device=x.device) if save_stats else None
+    if COMPUTE_DTYPE == _capi.BF16S and BF16_MEMO is not None:
+        # bf16 storage inside a training step: every LayerNorm result is the operand of a matrix product, so the kernel
+        # leaves its bf16 copy as well and the step's memo hands it to that product (no cast pass)
+        y16 = torch.empty((M, _bf16_pitch(d)), dtype=torch.bfloat16, device=x.device)
+        check(lib().capdec_layernorm_fwd_y16(ptr(x), ptr(gamma), ptr(beta), ptr(y), ptr(y16), y16.stride(0), ptr(mean),
+                                             ptr(rstd), M, d, float(eps), act, float(drop_p), int(seed), stream()),
+              "capdec_layernorm_fwd_y16")
+        BF16_MEMO[(y.data_ptr(), M, d, y.stride(0))] = (y, y16[:, :d])
+        return y, mean, rstd
     check(lib().capdec_layernorm_fwd(ptr(x), ptr(gamma), ptr(beta), ptr(y), ptr(mean), ptr(rstd), M, d, float(eps), act,
                                      float(drop_p), int(seed), stream()), "capdec_layernorm_fwd")
     return y, mean, rstd
 
 
 def layernorm_bwd(dy, x, gamma, beta, mean, rstd, act=ACT_NONE, drop_p=0.0, seed=0, drop2_p=0.0, seed2=0,
-                  want_dx_drop=False, dgamma=None, dbeta=None):
+                  want_dx_drop=False, dgamma=None, dbeta=None, dx_drop16=False):
+    """``dx_drop16``: dx_drop comes back as a bf16 matrix ONLY (capdec_layernorm_bwd_dx16; with drop2_p == 0 it is the bf16
+    copy of dx) -- for callers whose only readers of it are bf16-storage matrix products."""
     _mat(x, "layernorm_bwd.x"), _mat(dy, "layernorm_bwd.dy")
     if not (x.is_contiguous() and dy.is_contiguous()):
         raise _capi.CapdecError("layernorm_bwd: x and dy must be contiguous")
     M, d = x.shape
     dx = torch.empty_like(x)
-    dx_drop = torch.empty_like(x) if want_dx_drop else None
+    dx_drop = torch.empty_like(x) if want_dx_drop and not dx_drop16 else None
     if dgamma is None:
         dgamma = torch.empty(d, dtype=torch.float32, device=x.device)
     if dbeta is None:
         dbeta = torch.empty(d, dtype=torch.float32, device=x.device)
     l = lib()
     need = l.capdec_layernorm_bwd_workspace_bytes(M, d)
+    if dx_drop16:
+        dd16 = torch.empty((M, _bf16_pitch(d)), dtype=torch.bfloat16, device=x.device)
+        part = torch.empty(need, dtype=torch.uint8, device=x.device) if SIDE is not None else _capi.workspace(need, x.device)
+        check(l.capdec_layernorm_bwd_dx16(ptr(dy), ptr(x), ptr(gamma), ptr(beta), ptr(mean), ptr(rstd), ptr(dx), ptr(dd16),
+                                          dd16.stride(0), ptr(part), part.numel(), M, d, act, float(drop_p), int(seed),
+                                          float(drop2_p), int(seed2), stream()), "capdec_layernorm_bwd_dx16")
+        fin = lambda: check(l.capdec_layernorm_bwd_dparams(ptr(part), ptr(dgamma), ptr(dbeta), M, d, stream()),
+                            "capdec_layernorm_bwd_dparams")
+        if SIDE is not None:
+            SIDE.run(fin, part, dgamma, dbeta)
+        else:
+            fin()
+        return dx, dd16[:, :d], dgamma, dbeta
     if SIDE is not None:
         # the parameter gradients are weight gradients: their reduction runs on the weight-gradient lane, from a
         # private block of partials (the shared workspace would be overwritten by the next call on this stream)

@@ -162,6 +162,21 @@ int capdec_layernorm_bwd_dx(const void* dy, const void* x, const void* gamma, co
                             capdec_stream_t stream);
 int capdec_layernorm_bwd_dparams(const void* partials, void* dgamma, void* dbeta, int M, int d, capdec_stream_t stream);
 
+/* The same kernels with a bf16 output, for the CAPDEC_BF16S storage path (every LayerNorm result of the decoder, and
+ * every dx_drop, is the operand of a matrix product that reads bf16):
+ *   _fwd_y16   also writes y as a bf16 matrix y16 (row stride ldy16 in bf16 elements, a multiple of 8, >= d; padding
+ *              columns zero: capdec_cast_bf16's layout) next to the fp32 y the residual path needs;
+ *   _bwd_dx16  is capdec_layernorm_bwd_dx with dx_drop written as bf16 ONLY (dx_drop16, row stride lddd; with
+ *              drop2_p == 0 it is the bf16 copy of dx).  Follow it with capdec_layernorm_bwd_dparams as usual.
+ * Values are the fp32 results rounded to nearest even -- what capdec_cast_bf16 would make of them, minus the pass. */
+int capdec_layernorm_fwd_y16(const void* x, const void* gamma, const void* beta, void* y, void* y16, int ldy16, void* mean,
+                             void* rstd, int M, int d, float eps, int act, float drop_p, uint64_t drop_seed,
+                             capdec_stream_t stream);
+int capdec_layernorm_bwd_dx16(const void* dy, const void* x, const void* gamma, const void* beta, const void* mean,
+                              const void* rstd, void* dx, void* dx_drop16, int lddd, void* partials, size_t partials_bytes,
+                              int M, int d, int act, float drop_p, uint64_t drop_seed, float drop2_p, uint64_t drop2_seed,
+                              capdec_stream_t stream);
+
 /* capdec_layernorm_bwd_noalloc: capdec_layernorm_bwd for callers that CANNOT allocate or bring a workspace --
  * code under HIP graph capture, tight serving / fine-tuning loops, harnesses that forbid hipMalloc.  It has NO
  * counterpart in the reference (which never manages memory itself); same arguments minus the workspace, same

@@ -256,3 +256,36 @@ def test_attention_reads_bf16_keys_and_values(B, H, Tq, Tk, dh, causal):
     dq, dk, dv = ops.attn_bwd(q, k16, v16, o, do, lse, B, H, Tq, Tk, causal, 0.1, 5, dk=dbuf[:, :D], dv=dbuf[:, D:2 * D])
     assert torch.equal(dq, dq_ref)
     assert torch.equal(dk, dk_ref.to(torch.bfloat16)) and torch.equal(dv, dv_ref.to(torch.bfloat16))
+
+
+@pytest.mark.parametrize("M,d", [(37, 512), (20, 1024), (9, 200)])
+def test_layernorm_bf16_outputs_are_the_rounded_fp32_results(M, d):
+    """capdec_layernorm_fwd_y16 / capdec_layernorm_bwd_dx16: the bf16 outputs must be BIT-IDENTICAL to the fp32 entry
+    points' results rounded to nearest even (what a cast pass would have made of them), padding columns zero."""
+    ops = _ops()
+    from imagecaption_amd._capi import ACT_GELU
+    g = torch.Generator().manual_seed(M + d)
+    x, dy = torch.randn(M, d, generator=g).to(DEV), torch.randn(M, d, generator=g).to(DEV)
+    gamma, beta = torch.randn(d, generator=g).to(DEV), torch.randn(d, generator=g).to(DEV)
+    for act, p in ((0, 0.0), (ACT_GELU, 0.2)):
+        y_ref, mean, rstd = ops.layernorm_fwd(x, gamma, beta, act=act, drop_p=p, seed=3)
+        with ops.compute_dtype("bf16s"):
+            ops.BF16_MEMO = {}
+            try:
+                y, mean2, rstd2 = ops.layernorm_fwd(x, gamma, beta, act=act, drop_p=p, seed=3)
+                (src, y16), = ops.BF16_MEMO.values()
+            finally:
+                ops.BF16_MEMO = None
+        assert src is y and torch.equal(y, y_ref) and torch.equal(mean, mean2) and torch.equal(rstd, rstd2)
+        assert torch.equal(y16, y_ref.to(torch.bfloat16))
+        ld = y16.stride(0)
+        assert torch.all(torch.as_strided(y16, (M, ld), (ld, 1))[:, d:] == 0)
+        for p2 in (0.0, 0.3):
+            dx_ref, dd_ref, dg_ref, db_ref = ops.layernorm_bwd(dy, x, gamma, beta, mean, rstd, act=act, drop_p=p, seed=3,
+                                                               drop2_p=p2, seed2=8, want_dx_drop=True)
+            dx, dd16, dg, db = ops.layernorm_bwd(dy, x, gamma, beta, mean, rstd, act=act, drop_p=p, seed=3, drop2_p=p2,
+                                                 seed2=8, want_dx_drop=True, dx_drop16=True)
+            assert torch.equal(dx, dx_ref) and torch.equal(dg, dg_ref) and torch.equal(db, db_ref)
+            assert dd16.dtype == torch.bfloat16 and torch.equal(dd16, dd_ref.to(torch.bfloat16))
+            ld = dd16.stride(0)
+            assert torch.all(torch.as_strided(dd16, (M, ld), (ld, 1))[:, d:] == 0)

@@ -80,7 +80,8 @@ __device__ __forceinline__ void wait_images(int images) {
         case 4: asm volatile("s_waitcnt vmcnt(%0)" ::"n"(4 * NI) : "memory"); break;
         case 5: asm volatile("s_waitcnt vmcnt(%0)" ::"n"(5 * NI) : "memory"); break;
         case 6: asm volatile("s_waitcnt vmcnt(%0)" ::"n"(6 * NI) : "memory"); break;
-        default: asm volatile("s_waitcnt vmcnt(%0)" ::"n"(7 * NI) : "memory"); break;
+        case 7: asm volatile("s_waitcnt vmcnt(%0)" ::"n"(7 * NI) : "memory"); break;
+        default: asm volatile("s_waitcnt vmcnt(%0)" ::"n"(8 * NI <= 63 ? 8 * NI : 63) : "memory"); break;
     }
 }
 
@@ -116,6 +117,21 @@ __device__ __forceinline__ f32x16 mma_img_reg(const unsigned char* img, int foff
         acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, bfrag[ks], acc, 0, 0, 0);
     }
     return acc;
+}
+
+// accT += image x frag^T (image rows on the accumulator rows) and acc += frag x image^T (image rows on the lanes) from
+// ONE read of each image fragment: the A and B register layouts of this MFMA are the same
+template <int DH>
+__device__ __forceinline__ void mma_img_reg_both(f32x16& accT, f32x16& acc, const unsigned char* img, int foff,
+                                                 const bf16x8a* frag) {
+#pragma unroll
+    for (int r = 0; r < 16; ++r) accT[r] = acc[r] = 0.f;
+#pragma unroll
+    for (int ks = 0; ks < DH / 16; ++ks) {
+        const bf16x8a a = *reinterpret_cast<const bf16x8a*>(img + (foff ^ (ks << 5)));
+        accT = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, frag[ks], accT, 0, 0, 0);
+        acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(frag[ks], a, acc, 0, 0, 0);
+    }
 }
 
 // byte offsets of the two transposing reads that make the A fragment "column block 0 of the image, transposed":
@@ -441,6 +457,164 @@ __global__ __launch_bounds__(64) void attn16_bwd_dkv_kernel(Attn16Params p) {
     }
 }
 
+// Backward when all queries of a (b, h) fit one tile (Tq <= 32: the training shapes C2 / C3): ONE wave per (b, h) walks
+// the key tiles once and produces dQ, dK and dV together -- K and V are read once (the two-kernel form reads them
+// twice, and its dK/dV waves re-read Q and dO once per key tile), dK / dV of a tile are complete when the tile is
+// done.  Q and dO stay in LDS for the whole walk (their transposes feed dK^T += Q^T dS, dV^T += dO^T Pd) and in
+// registers in fragment form; the scores are computed in both orientations from one read of the K / V fragments
+// (query on the lanes for dQ, key on the lanes for dK / dV): 16 extra MFMAs per tile instead of moving P between lanes.
+template <int DH>
+__global__ __launch_bounds__(64) void attn16_bwd_fused_kernel(Attn16Params p) {
+    using L = Img<DH>;
+    constexpr int NST = L::NST, NI = L::NI;
+    __shared__ __attribute__((aligned(1024))) unsigned char smem[(2 + NST * 2) * L::BYTES];
+    __shared__ float line[32];
+    unsigned char* Qs = smem;
+    unsigned char* dOs = smem + L::BYTES;
+    unsigned char* ring = smem + 2 * L::BYTES;
+    const int lane = threadIdx.x, l31 = lane & 31, half = lane >> 5;
+    int bh, qt;
+    attn_item(p.B * p.H, 1, false, bh, qt);
+    const int b = bh / p.H, h = bh % p.H;
+    const int off = p.Tk - p.Tq;
+    const int query = l31;
+    const __bf16* kg = p.k + (size_t)b * p.Tk * p.ldk + h * DH;
+    const __bf16* vg = p.v + (size_t)b * p.Tk * p.ldv + h * DH;
+    int kmax = p.Tk;
+    if (p.causal) kmax = min(p.Tk, 32 + off);
+    const int nkt = kmax > 0 ? (kmax + 31) / 32 : 0;
+
+    // register loads first (they are then older than every DMA and the image counts below are exact)
+    bf16x8a of[DH / 16];
+    row_frags<DH>(of, p.o + (size_t)b * p.Tq * p.ldo + h * DH, p.ldo, query, p.Tq, half);
+    const float lse = query < p.Tq ? p.lse[(size_t)bh * p.Tq + query] : INFINITY;
+    float la[16], da[16];
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+        const int qq = row_of(r, half);
+        la[r] = qq < p.Tq ? p.lse[(size_t)bh * p.Tq + qq] : INFINITY;
+    }
+    dma_image<DH>(Qs, p.q + (size_t)b * p.Tq * p.ldq + h * DH, p.ldq, 0, p.Tq, lane);
+    dma_image<DH>(dOs, p.dout + (size_t)b * p.Tq * p.lddo + h * DH, p.lddo, 0, p.Tq, lane);
+#pragma unroll
+    for (int s = 0; s < NST; ++s) {
+        if (s < nkt) {
+            dma_image<DH>(ring + s * 2 * L::BYTES, kg, p.ldk, s * 32, p.Tk, lane);
+            dma_image<DH>(ring + s * 2 * L::BYTES + L::BYTES, vg, p.ldv, s * 32, p.Tk, lane);
+        }
+    }
+    const int foff = frag_off<DH>(l31, half);
+    int toff[2];
+    tr_offs<DH>(lane, toff);
+    wait_images<NI>(2 * max(min(nkt, NST) - 1, 0));  // Q, dO and the first key tile have landed
+    bf16x8a qf[DH / 16], dof[DH / 16];
+#pragma unroll
+    for (int ks = 0; ks < DH / 16; ++ks) {
+        qf[ks] = *reinterpret_cast<const bf16x8a*>(Qs + (foff ^ (ks << 5)));
+        dof[ks] = *reinterpret_cast<const bf16x8a*>(dOs + (foff ^ (ks << 5)));
+    }
+    float dsum = 0.f;
+#pragma unroll
+    for (int ks = 0; ks < DH / 16; ++ks)
+#pragma unroll
+        for (int e = 0; e < 8; ++e) dsum = __fmaf_rn((float)dof[ks][e], (float)of[ks][e], dsum);
+    dsum += __shfl_xor(dsum, 32, 64);
+    if (lane < 32) {
+        line[lane] = dsum;
+        if (query < p.Tq) p.delta[(size_t)bh * p.Tq + query] = dsum;
+    }
+    __syncthreads();
+#pragma unroll
+    for (int r = 0; r < 16; ++r) da[r] = line[row_of(r, half)];
+
+    f32x16 dqacc[DH / 32];
+#pragma unroll
+    for (int dt = 0; dt < DH / 32; ++dt)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) dqacc[dt][r] = 0.f;
+    for (int kt = 0; kt < nkt; ++kt) {
+        const int k0 = kt * 32;
+        const int key = k0 + l31;
+        unsigned char* Ks = ring + (kt % NST) * 2 * L::BYTES;
+        unsigned char* Vs = Ks + L::BYTES;
+        f32x16 sT, s, dpT, dp;  // (this tile's images have landed: prologue / end of the previous iteration)
+        mma_img_reg_both<DH>(sT, s, Ks, foff, qf);     // S^T[key][query], S[query][key]
+        mma_img_reg_both<DH>(dpT, dp, Vs, foff, dof);  // dP^T[key][query], dP[query][key]
+        {   // query on the lanes: dQ^T[dh][query] += K^T dS^T
+            float ds[16];
+            const uint32_t base = ((uint32_t)bh * (uint32_t)p.Tq + (uint32_t)query) * (uint32_t)p.Tk + (uint32_t)k0;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int kk = k0 + row_of(r, half);
+                const bool vis = kk < p.Tk && (!p.causal || kk <= query + off);
+                const float pv = vis ? __expf(sT[r] * p.scale - lse) : 0.f;
+                float g = dpT[r];
+                if (p.drop.on()) g = p.drop.apply(g, base + (uint32_t)row_of(r, half));
+                ds[r] = pv * (g - dsum);
+            }
+            bf16x8a db[2];
+            pack_rows(db, ds);
+            mma_trimg_acc<DH>(dqacc, Ks, toff, db);
+        }
+        {   // key on the lanes: dV^T[dh][key] = dO^T Pd, dK^T[dh][key] = Q^T dS -- complete for this tile
+            float pd[16], ds[16];
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int qq = row_of(r, half);
+                const bool vis = key < p.Tk && qq < p.Tq && (!p.causal || key <= qq + off);
+                const float pv = vis ? __expf(s[r] * p.scale - la[r]) : 0.f;
+                float pdr = pv, gr = dp[r];
+                if (p.drop.on()) {
+                    const uint32_t idx = ((uint32_t)bh * (uint32_t)p.Tq + (uint32_t)qq) * (uint32_t)p.Tk + (uint32_t)key;
+                    const bool keep = p.drop.keep(idx);
+                    pdr = keep ? pv * p.drop.scale : 0.f;
+                    gr = keep ? gr * p.drop.scale : 0.f;
+                }
+                pd[r] = pdr;
+                ds[r] = pv * (gr - da[r]);
+            }
+            bf16x8a pb[2], sb[2];
+            pack_rows(pb, pd);
+            pack_rows(sb, ds);
+            f32x16 dkacc[DH / 32], dvacc[DH / 32];
+#pragma unroll
+            for (int dt = 0; dt < DH / 32; ++dt)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) dkacc[dt][r] = dvacc[dt][r] = 0.f;
+            mma_trimg_acc<DH>(dvacc, dOs, toff, pb);
+            mma_trimg_acc<DH>(dkacc, Qs, toff, sb);
+            // The NEXT tile is awaited here, BEFORE this tile's stores are issued: loads and stores retire through one
+            // in-order counter, so a wait placed after the stores would also wait for their acknowledgements (a
+            // store round trip per tile: 211 -> 172 us was all the one-walk form gained with the wait at the top).
+            // Requested so far: tiles up to kt + NST - 1; everything older than the tiles after kt + 1 must be done.
+            if (kt + 1 < nkt) wait_images<NI>(2 * min(nkt - 2 - kt, NST - 2));
+            if (key < p.Tk) {
+                store_row<DH>(p.dk + ((size_t)b * p.Tk + key) * p.lddk + h * DH, dkacc, p.scale, half);
+                store_row<DH>(p.dv + ((size_t)b * p.Tk + key) * p.lddv + h * DH, dvacc, 1.f, half);
+            }
+        }
+        if (kt + NST < nkt) {
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            dma_image<DH>(Ks, kg, p.ldk, k0 + NST * 32, p.Tk, lane);
+            dma_image<DH>(Vs, vg, p.ldv, k0 + NST * 32, p.Tk, lane);
+        }
+    }
+    // causal with fewer visible keys than Tk: the key tiles past the last visible one get zero gradients
+    for (int k0 = nkt * 32; k0 < p.Tk; k0 += 32) {
+        const int key = k0 + l31;
+        if (key < p.Tk) {
+            f32x16 z[DH / 32];
+#pragma unroll
+            for (int dt = 0; dt < DH / 32; ++dt)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) z[dt][r] = 0.f;
+            store_row<DH>(p.dk + ((size_t)b * p.Tk + key) * p.lddk + h * DH, z, 0.f, half);
+            store_row<DH>(p.dv + ((size_t)b * p.Tk + key) * p.lddv + h * DH, z, 0.f, half);
+        }
+    }
+    if (query < p.Tq) store_row<DH>(p.dq + ((size_t)b * p.Tq + query) * p.lddq + h * DH, dqacc, p.scale, half);
+}
+
 static bool ok_mat16(const void* p, int ld, int H, int dh, int rows) {
     return p && aligned16(p) && ld % 8 == 0 && ld >= H * dh && (uint64_t)rows * (uint64_t)ld < (1ull << 31);
 }
@@ -448,6 +622,13 @@ static bool ok_mat16(const void* p, int ld, int H, int dh, int rows) {
 }  // namespace capdec
 
 using namespace capdec;
+
+// CAPDEC_ATTN16_SPLIT_BWD=1 (read once): capdec_attn_bwd_bf16 takes the two-kernel form at every shape -- for the
+// tests that compare the two forms and for measurements
+static const bool g_attn16_split_bwd = [] {
+    const char* e = getenv("CAPDEC_ATTN16_SPLIT_BWD");
+    return e && e[0] == '1';
+}();
 
 static int attn16_check(const char* what, int B, int H, int Tq, int Tk, int dh) {
     CAPDEC_REQUIRE(B > 0 && H > 0 && Tq > 0 && Tk > 0, "%s: bad shape B=%d H=%d Tq=%d Tk=%d", what, B, H, Tq, Tk);
@@ -499,6 +680,11 @@ extern "C" int capdec_attn_bwd_bf16(const void* q16, int ldq, const void* k16, i
     p.drop = make_dropout(drop_p, drop_seed);
     hipStream_t st = (hipStream_t)stream;
     const dim3 gq(B * H * ((Tq + 31) / 32)), gk(B * H * ((Tk + 31) / 32));
+    if (Tq <= 32 && !g_attn16_split_bwd) {  // one query tile: dQ, dK and dV in one walk over the keys
+        if (dh == 64) hipLaunchKernelGGL(attn16_bwd_fused_kernel<64>, dim3(B * H), dim3(64), 0, st, p);
+        else hipLaunchKernelGGL(attn16_bwd_fused_kernel<128>, dim3(B * H), dim3(64), 0, st, p);
+        return check_launch("capdec_attn_bwd_bf16");
+    }
     if (dh == 64) {
         hipLaunchKernelGGL(attn16_bwd_dq_kernel<64>, gq, dim3(64), 0, st, p);
         hipLaunchKernelGGL(attn16_bwd_dkv_kernel<64>, gk, dim3(64), 0, st, p);

@@ -29,6 +29,8 @@ SHAPES = [
     (1, 1, 40, 75, 128, True),     # causal with more keys than queries (offset 35)
     (2, 2, 5, 1, 64, False),       # one key
     (1, 2, 299, 299, 64, True),    # C1 caption length: ten tiles, ring of four images wraps
+    (2, 2, 20, 50, 64, True),      # one query tile (the one-walk backward), causal with an offset of 30
+    (1, 2, 7, 100, 128, True),     # one query tile, more key tiles than the ring holds
 ]
 
 
@@ -92,7 +94,7 @@ def test_bf16_attention_matches_float64_on_rounded_inputs(B, H, Tq, Tk, dh, caus
         assert emax < 2 * TOL_MAX and erms < 2 * TOL_RMS, (name, emax, erms)
 
 
-@pytest.mark.parametrize("B,H,Tq,Tk,dh,causal", SHAPES[:6])
+@pytest.mark.parametrize("B,H,Tq,Tk,dh,causal", SHAPES[:6] + SHAPES[8:])
 def test_bf16_attention_uses_the_fp32_kernels_dropout_masks(B, H, Tq, Tk, dh, causal):
     ops = _ops()
     q, k, v, do = _inputs(B, H, Tq, Tk, dh, 5 * Tq + Tk)

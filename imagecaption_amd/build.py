@@ -15,6 +15,12 @@ CSRC = os.path.join(HERE, "csrc")
 OBJ = os.path.join(CSRC, "_build")
 LIB = os.path.join(HERE, "libcapdec.so")
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-fno-gpu-rdc", "-Wall", "-Wno-unused-function"]
+# Per-file extras.  -amdgpu-mfma-vgpr-form: MFMA accumulators live in ordinary VGPRs (gfx950 has one unified register
+# file) instead of AGPRs -- kernels that touch their accumulators with vector instructions between products (softmax
+# rescale, masking, bf16 packing, stores) otherwise pay a v_accvgpr_read / _write pair around every such touch.
+FILE_FLAGS = {
+    "attention_bf16.hip": ["-mllvm", "-amdgpu-mfma-vgpr-form=1"],
+}
 
 
 def _hipcc():
@@ -43,7 +49,7 @@ def build(force=False, verbose=True):
 
     def run(job):
         src, obj = job
-        cmd = [hipcc] + FLAGS + ["-c", src, "-o", obj]
+        cmd = [hipcc] + FLAGS + FILE_FLAGS.get(os.path.basename(src), []) + ["-c", src, "-o", obj]
         r = subprocess.run(cmd, capture_output=True, text=True)
         if r.returncode != 0:
             raise RuntimeError(f"hipcc failed for {src}:\n{r.stderr[-4000:]}")

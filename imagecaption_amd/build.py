@@ -23,6 +23,9 @@ FILE_FLAGS = {
 }
 
 
+EXTRA = os.environ.get("CAPDEC_EXTRA_FLAGS", "").split()  # diagnostic builds (-DCAPDEC_...); never set by the package
+
+
 def _hipcc():
     for c in (os.environ.get("HIPCC"), "/opt/rocm/bin/hipcc", "hipcc"):
         if c and (os.path.isabs(c) and os.path.exists(c) or not os.path.isabs(c)):
@@ -49,7 +52,7 @@ def build(force=False, verbose=True):
 
     def run(job):
         src, obj = job
-        cmd = [hipcc] + FLAGS + FILE_FLAGS.get(os.path.basename(src), []) + ["-c", src, "-o", obj]
+        cmd = [hipcc] + FLAGS + FILE_FLAGS.get(os.path.basename(src), []) + EXTRA + ["-c", src, "-o", obj]
         r = subprocess.run(cmd, capture_output=True, text=True)
         if r.returncode != 0:
             raise RuntimeError(f"hipcc failed for {src}:\n{r.stderr[-4000:]}")

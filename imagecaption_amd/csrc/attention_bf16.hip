@@ -187,6 +187,34 @@ __device__ __forceinline__ void store_row(__bf16* dst, const f32x16* acc, float 
         }
 }
 
+// The same rows through a (free) LDS image, so that global memory sees whole rows: the accumulator layout gives a
+// lane 8-byte pieces of ITS row (32 rows per store instruction, 16 bytes each: a quarter of every 64-byte sector
+// per request), the image gives 16 consecutive lanes one 256- or 128-byte row (the DMA's mapping, run backwards).
+// One wave, LDS operations execute in order; the barrier only keeps the compiler from reordering them.
+template <int DH>
+__device__ __forceinline__ void store_rows_via_lds(unsigned char* img, __bf16* g, int ld, int row0, int T, const f32x16* acc,
+                                                   float mul, int lane) {
+    using L = Img<DH>;
+    const int l31 = lane & 31, half = lane >> 5;
+#pragma unroll
+    for (int dt = 0; dt < DH / 32; ++dt)
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            bf16x4a v;
+#pragma unroll
+            for (int j = 0; j < 4; ++j) v[j] = (__bf16)(acc[dt][4 * i + j] * mul);
+            *reinterpret_cast<bf16x4a*>(img + l31 * L::ROWB + (((4 * dt + i) ^ L::swz(l31)) << 4) + 8 * half) = v;
+        }
+    __syncthreads();
+#pragma unroll
+    for (int j = 0; j < L::NI; ++j) {
+        const int r = j * (64 / L::PPR) + lane / L::PPR;
+        const int piece = (lane % L::PPR) ^ L::swz(r);
+        const uint4 v = *reinterpret_cast<const uint4*>(img + j * 1024 + lane * 16);
+        if (row0 + r < T) *reinterpret_cast<uint4*>(g + (size_t)(row0 + r) * ld + piece * 8) = v;
+    }
+}
+
 template <int DH>
 __global__ __launch_bounds__(64) void attn16_fwd_kernel(Attn16Params p) {
     using L = Img<DH>;
@@ -451,10 +479,10 @@ __global__ __launch_bounds__(64) void attn16_bwd_dkv_kernel(Attn16Params p) {
             dma_image<DH>(dOs, dog, p.lddo, q0 + NST * 32, p.Tq, lane);
         }
     }
-    if (key < p.Tk) {
-        store_row<DH>(p.dk + ((size_t)b * p.Tk + key) * p.lddk + h * DH, dkacc, p.scale, half);
-        store_row<DH>(p.dv + ((size_t)b * p.Tk + key) * p.lddv + h * DH, dvacc, 1.f, half);
-    }
+    // every DMA has landed and been consumed: the ring is free
+    __syncthreads();
+    store_rows_via_lds<DH>(smem, p.dk + (size_t)b * p.Tk * p.lddk + h * DH, p.lddk, k0, p.Tk, dkacc, p.scale, lane);
+    store_rows_via_lds<DH>(smem + L::BYTES, p.dv + (size_t)b * p.Tk * p.lddv + h * DH, p.lddv, k0, p.Tk, dvacc, 1.f, lane);
 }
 
 // Backward when all queries of a (b, h) fit one tile (Tq <= 32: the training shapes C2 / C3): ONE wave per (b, h) walks
@@ -588,10 +616,9 @@ __global__ __launch_bounds__(64) void attn16_bwd_fused_kernel(Attn16Params p) {
             // store round trip per tile: 211 -> 172 us was all the one-walk form gained with the wait at the top).
             // Requested so far: tiles up to kt + NST - 1; everything older than the tiles after kt + 1 must be done.
             if (kt + 1 < nkt) wait_images<NI>(2 * min(nkt - 2 - kt, NST - 2));
-            if (key < p.Tk) {
-                store_row<DH>(p.dk + ((size_t)b * p.Tk + key) * p.lddk + h * DH, dkacc, p.scale, half);
-                store_row<DH>(p.dv + ((size_t)b * p.Tk + key) * p.lddv + h * DH, dvacc, 1.f, half);
-            }
+            // through this tile's own K / V images (every read of them is done)
+            store_rows_via_lds<DH>(Ks, p.dk + (size_t)b * p.Tk * p.lddk + h * DH, p.lddk, k0, p.Tk, dkacc, p.scale, lane);
+            store_rows_via_lds<DH>(Vs, p.dv + (size_t)b * p.Tk * p.lddv + h * DH, p.lddv, k0, p.Tk, dvacc, 1.f, lane);
         }
         if (kt + NST < nkt) {
             asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");

@@ -30,7 +30,7 @@ for name, B, H, Tq, Tk, dh, causal in SHAPES:
     kv32 = torch.randn(B * Tk, 2 * D, generator=g).cuda()
     do32 = torch.randn(B * Tq, D, generator=g).cuda()
     q16, kv16, do16 = q32.bfloat16(), kv32.bfloat16(), do32.bfloat16()
-    p, seed = 0.1, 7
+    p, seed = float(os.environ.get("ATTN_P", "0.1")), 7
     o32, lse = ops.attn_fwd(q32[:, :D], kv32[:, :D], kv32[:, D:], B, H, Tq, Tk, causal, p, seed)
     o16, lse16 = ops.attn_fwd(q16[:, :D], kv16[:, :D], kv16[:, D:], B, H, Tq, Tk, causal, p, seed)
     dq32, dkv32 = torch.empty_like(do32), torch.empty_like(kv32)

@@ -94,10 +94,12 @@ def test_kv_cached_step_logits_equal_full_prefix_forward():
             assert err < 2e-5, (t, float(err))
 
 
-def test_bleu4_gate_reference_shape_greedy_vs_oracle():
+@pytest.mark.parametrize("n,T", [(24, 24), (12, 200)])
+def test_bleu4_gate_reference_shape_greedy_vs_oracle(n, T):
     """north_star gate: BLEU-4 on test captions within 0.1 (BLEU points) of the oracle with the same
-    weights.  Reference shape (d=512, 8 heads, 6 layers, V=108, S=1), 24 real test captions as references,
-    synthetic 768-d features, random-init weights (no checkpoint ships), greedy length 24."""
+    weights.  Reference shape (d=512, 8 heads, 6 layers, V=108, S=1), real test captions as references,
+    synthetic 768-d features, random-init weights (no checkpoint ships), greedy length 24 and 200, the reference default (the oracle
+    re-runs the whole prefix per step on the host: a dozen captions at that length)."""
     import json
     from imagecaption_amd import ImageCaptioningModel
     from imagecaption_amd.bleu import bleu_1_4
@@ -110,7 +112,6 @@ def test_bleu4_gate_reference_shape_greedy_vs_oracle():
     model = ImageCaptioningModel(108)
     model.load_state_dict(ref.state_dict())
     dec = CaptionDecoder(model.to(DEV))
-    n, T = 24, 24
     feats = torch.randn(n, 768, generator=torch.Generator().manual_seed(5))
     caps = np.load(os.path.join(GOLDEN, "captions_test.npz"))
     ends = np.cumsum(caps["lengths"].astype(np.int64))
@@ -149,6 +150,7 @@ def _sampler_models(bias_period=0.0, bias_end=0.0, S=1):
     (0.0, 0.0, 24, 10, 5),      # never stops early: forced END in the last two steps
     (6.0, 0.0, 60, 3, 2),       # sentences complete -> stop by max_sentences, rows closed with END
     (5.0, 4.0, 40, 2, 1),       # END boosted once a row has enough sentences; late-phase boosts (i >= 0.9 max_len)
+    (0.0, 0.0, 200, 100, 5),    # the reference's default max_len (train.py:289): 199 cached steps, 1194 draws
 ])
 def test_reference_sampler_token_exact_given_the_same_uniforms(bias_period, bias_end, max_len, max_sentences, min_words):
     from imagecaption_amd.decode import CaptionDecoder

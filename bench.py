@@ -456,7 +456,7 @@ def main():
     ap.add_argument("--decode-images", type=int, default=12500,
                     help="images per GPU for the decode leg (BASELINE configs[4]: 100k images over 8 GPUs)")
     ap.add_argument("--detail", action="store_true", help="print the per-shape kernel table to stderr")
-    ap.add_argument("--no-modes", action="store_true", help="skip the f32x3 / bf16 legs of the default fp32 run")
+    ap.add_argument("--no-modes", action="store_true", help="skip the f32x3 / bf16 / bf16s legs of the default fp32 run")
     ap.add_argument("--no-legs", action="store_true", help="skip the C1 (fp32) and C3 (bf16) legs of the default run")
     ap.add_argument("--cpu-full", action="store_true", help="CPU baseline also for C3 (3 steps) and beam-5 (256 images): minutes")
     ap.add_argument("--no-tune", action="store_true", help="keep the cost model's GEMM plans (skip the measured-plan set-up)")
@@ -525,10 +525,10 @@ def main():
 
     # the instrumented step contains the gradient all-reduce: every rank must run it
     agg, detail = profile_step(trainer, feats, ids)
-    # the same step in the two optional arithmetic modes (never the headline `value`; N = 1 only, like cpu_baseline)
+    # the same step in the optional arithmetic modes (never the headline `value`; N = 1 only, like cpu_baseline)
     modes = {}
     if args.dtype == "fp32" and not args.no_modes and world == 1:
-        for mode in ("f32x3", "bf16"):
+        for mode in ("f32x3", "bf16", "bf16s"):
             torch.manual_seed(42)
             m2 = ImageCaptioningModel(cfg["vocab"], cfg["d"], cfg["heads"], cfg["layers"], feature_dim=cfg["din"]).to(dev)
             m2.train()
@@ -539,8 +539,10 @@ def main():
             dt2, loss2 = timed_steps(t2, feats, ids, args.steps, args.warmup, world, dev)
             modes[mode] = {"value": cfg["batch"] * world * args.steps / dt2, "unit": "images/s",
                            "ms_per_step": dt2 / args.steps * 1e3, "loss": float(loss2.item()),
-                           "arithmetic": "fp32 operands split into 3 bf16 terms, six bf16 MFMA products, fp32-level accuracy"
-                           if mode == "f32x3" else "bf16 MFMA products, fp32 accumulate / storage / optimizer"}
+                           "arithmetic": {"f32x3": "fp32 operands split into 3 bf16 terms, six bf16 MFMA products, fp32-level accuracy",
+                                          "bf16": "bf16 MFMA products, fp32 accumulate / storage / optimizer",
+                                          "bf16s": "bf16 storage of every matrix-product and attention operand (the C3 "
+                                                   "leg's mode), fp32 accumulate / norms / loss / master weights / optimizer"}[mode]}
             del t2, m2
     # the other BASELINE configurations, timed by the same harness in the same run (N = 1 only, like cpu_baseline)
     legs = {}

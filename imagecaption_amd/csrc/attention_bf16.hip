@@ -149,19 +149,41 @@ __device__ __forceinline__ void tr_offs(int lane, int* toff) {
         toff[rd] = kr * L::ROWB + ((low ^ L::swz(kr)) << 4) + 8 * (p4 & 1);
     }
 }
+// The transposing reads are issued as inline assembly: the compiler puts s_waitcnt vmcnt(0) in front of every
+// ds_read_b64_tr_b16 BUILTIN while an LDS DMA is in flight (it cannot tell that the DMA targets another ring slot; the
+// plain ds_read_b128 loads get no such wait), which drains the ring -- every tile then pays a full memory latency.
+// The pacing is explicit anyway (wait_images), so the reads below are invisible to that pass and the lgkmcnt wait
+// that their results need is issued here.
+__device__ __forceinline__ unsigned lds_addr(const unsigned char* p) {
+    return (unsigned)(size_t)(const __attribute__((address_space(3))) unsigned char*)p;
+}
+__device__ __forceinline__ s16x4a lds_read_tr16(unsigned addr) {
+    s16x4a v;
+    asm volatile("ds_read_b64_tr_b16 %0, %1" : "=v"(v) : "v"(addr));
+    return v;
+}
 // out[dt] += image^T (column block dt, rows 16 m ..) x bfrag  for the two 16-row runs m of the image
 template <int DH>
 __device__ __forceinline__ void mma_trimg_acc(f32x16* out, const unsigned char* img, const int* toff, const bf16x8a* bfrag) {
     using L = Img<DH>;
+    constexpr int NDT = DH / 32;
+    const unsigned base = lds_addr(img);
 #pragma unroll
     for (int m = 0; m < 2; ++m) {
+        s16x4a lo[NDT], hi[NDT];
 #pragma unroll
-        for (int dt = 0; dt < DH / 32; ++dt) {
-            const s16x4a lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16(
-                (s16x4a __attribute__((address_space(3)))*)(img + m * 16 * L::ROWB + (toff[0] ^ (dt << 6))));
-            const s16x4a hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16(
-                (s16x4a __attribute__((address_space(3)))*)(img + m * 16 * L::ROWB + (toff[1] ^ (dt << 6))));
-            const s16x8a v = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+        for (int dt = 0; dt < NDT; ++dt) {
+            lo[dt] = lds_read_tr16(base + m * 16 * L::ROWB + (toff[0] ^ (dt << 6)));
+            hi[dt] = lds_read_tr16(base + m * 16 * L::ROWB + (toff[1] ^ (dt << 6)));
+        }
+        if constexpr (NDT == 4)
+            asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(lo[0]), "+v"(hi[0]), "+v"(lo[1]), "+v"(hi[1]), "+v"(lo[2]), "+v"(hi[2]),
+                         "+v"(lo[3]), "+v"(hi[3]));
+        else
+            asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(lo[0]), "+v"(hi[0]), "+v"(lo[1]), "+v"(hi[1]));
+#pragma unroll
+        for (int dt = 0; dt < NDT; ++dt) {
+            const s16x8a v = {lo[dt][0], lo[dt][1], lo[dt][2], lo[dt][3], hi[dt][0], hi[dt][1], hi[dt][2], hi[dt][3]};
             out[dt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8a, v), bfrag[m], out[dt], 0, 0, 0);
         }
     }
@@ -190,7 +212,7 @@ __device__ __forceinline__ void store_row(__bf16* dst, const f32x16* acc, float 
 // The same rows through a (free) LDS image, so that global memory sees whole rows: the accumulator layout gives a
 // lane 8-byte pieces of ITS row (32 rows per store instruction, 16 bytes each: a quarter of every 64-byte sector
 // per request), the image gives 16 consecutive lanes one 256- or 128-byte row (the DMA's mapping, run backwards).
-// One wave, LDS operations execute in order; the barrier only keeps the compiler from reordering them.
+// One wave, LDS operations execute in order; the wait between the two phases is for the compiler's benefit.
 template <int DH>
 __device__ __forceinline__ void store_rows_via_lds(unsigned char* img, __bf16* g, int ld, int row0, int T, const f32x16* acc,
                                                    float mul, int lane) {
@@ -205,7 +227,7 @@ __device__ __forceinline__ void store_rows_via_lds(unsigned char* img, __bf16* g
             for (int j = 0; j < 4; ++j) v[j] = (__bf16)(acc[dt][4 * i + j] * mul);
             *reinterpret_cast<bf16x4a*>(img + l31 * L::ROWB + (((4 * dt + i) ^ L::swz(l31)) << 4) + 8 * half) = v;
         }
-    __syncthreads();
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");  // (not __syncthreads(): its fence would drain vmcnt as well)
 #pragma unroll
     for (int j = 0; j < L::NI; ++j) {
         const int r = j * (64 / L::PPR) + lane / L::PPR;

@@ -84,6 +84,8 @@ SIGNATURES = {
     "capdec_probe_copy": (_i, [_vp, _vp, _sz, _vp]),
     "capdec_cross1_fwd": (_i, [_vp, _vp, _vp, _vp, _i, _i, _i, _i, _f, _u64, _f, _u64, _vp]),
     "capdec_cross1_bwd": (_i, [_vp, _vp, _vp, _i, _i, _i, _i, _f, _u64, _vp]),
+    "capdec_cross1_spread": (_i, [_vp, _i, _vp, _i, _i, _i, _vp]),
+    "capdec_cross1_gather": (_i, [_vp, _vp, _vp, _i, _vp, _i, _vp, _i, _i, _i, _vp]),
     "capdec_pe_add": (_i, [_vp, _vp, _vp, _i, _i, _i, _i, _i, _f, _u64, _vp]),
     "capdec_act_dropout_bwd": (_i, [_vp, _vp, _vp, _sz, _f, _u64, _vp]),
 }

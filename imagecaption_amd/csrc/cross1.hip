@@ -85,6 +85,45 @@ __global__ __launch_bounds__(256) void cross1_bwd_kernel(Cross1Params p) {
     }
 }
 
+// The two reshapes around the B*H-row products of this branch (they used to be torch elementwise / diagonal / sum
+// calls on the training path):
+//   spread: vblk[(b, h), j] = v[b, j] inside head h's slice, 0 elsewhere (the out-projection's operand);
+//   gather: dk[b, :] = 0 (exactly, as torch computes it), dv[b, j] = dvblk[(b, head of j), j], and
+//           dbias[j] = sum_b dbias_part[b, j] in image order (fixed: bitwise reproducible).
+__global__ __launch_bounds__(256) void cross1_spread_kernel(const float* __restrict__ v, int ldv, float* __restrict__ vblk,
+                                                            int B, int H, int d) {
+    const int c4 = d / 4, dh = d / H;
+    const size_t idx = (size_t)blockIdx.x * 256 + threadIdx.x;
+    if (idx >= (size_t)B * H * c4) return;
+    const int row = (int)(idx / c4), c = (int)(idx % c4);
+    const int b = row / H, h = row % H;
+    float4 x = make_float4(0.f, 0.f, 0.f, 0.f);
+    if ((c * 4) / dh == h) x = *reinterpret_cast<const float4*>(v + (size_t)b * ldv + c * 4);
+    *reinterpret_cast<float4*>(vblk + (size_t)row * d + c * 4) = x;
+}
+
+__global__ __launch_bounds__(256) void cross1_gather_kernel(const float* __restrict__ dvblk, const float* __restrict__ dbias_part,
+                                                            float* __restrict__ dk, int lddk, float* __restrict__ dv, int lddv,
+                                                            float* __restrict__ dbias, int B, int H, int d) {
+    const int c4 = d / 4, dh = d / H;
+    const size_t idx = (size_t)blockIdx.x * 256 + threadIdx.x;
+    if (idx < (size_t)B * c4) {
+        const int b = (int)(idx / c4), c = (int)(idx % c4);
+        const int h = (c * 4) / dh;
+        *reinterpret_cast<float4*>(dk + (size_t)b * lddk + c * 4) = make_float4(0.f, 0.f, 0.f, 0.f);
+        *reinterpret_cast<float4*>(dv + (size_t)b * lddv + c * 4) =
+            *reinterpret_cast<const float4*>(dvblk + (size_t)(b * H + h) * d + c * 4);
+    }
+    if (idx < (size_t)c4) {  // the first c4 threads also fold the per-image bias partials
+        float4 s = make_float4(0.f, 0.f, 0.f, 0.f);
+        for (int b = 0; b < B; ++b) {
+            const float4 a = *reinterpret_cast<const float4*>(dbias_part + (size_t)b * d + idx * 4);
+            s.x += a.x; s.y += a.y; s.z += a.z; s.w += a.w;
+        }
+        *reinterpret_cast<float4*>(dbias + idx * 4) = s;
+    }
+}
+
 }  // namespace capdec
 
 using namespace capdec;
@@ -134,4 +173,27 @@ extern "C" int capdec_cross1_bwd(const void* g, void* dU, void* dbias_part, int 
         default: hipLaunchKernelGGL(cross1_bwd_kernel<16>, grid, dim3(256), 0, st, p); break;
     }
     return check_launch("capdec_cross1_bwd");
+}
+
+extern "C" int capdec_cross1_spread(const void* v, int ldv, void* vblk, int B, int H, int d, capdec_stream_t stream) {
+    if (int rc = cross1_check("capdec_cross1_spread", B, 1, H, d)) return rc;
+    CAPDEC_REQUIRE(v && vblk && aligned16(v) && aligned16(vblk) && ldv % 4 == 0 && ldv >= d && (d / H) % 4 == 0,
+                   "capdec_cross1_spread: operands must be non-null, 16-byte aligned, ldv %% 4 == 0, ldv >= d, head dim %% 4 == 0");
+    const size_t total = (size_t)B * H * (d / 4);
+    hipLaunchKernelGGL(cross1_spread_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, (hipStream_t)stream,
+                       (const float*)v, ldv, (float*)vblk, B, H, d);
+    return check_launch("capdec_cross1_spread");
+}
+
+extern "C" int capdec_cross1_gather(const void* dvblk, const void* dbias_part, void* dk, int lddk, void* dv, int lddv,
+                                    void* dbias, int B, int H, int d, capdec_stream_t stream) {
+    if (int rc = cross1_check("capdec_cross1_gather", B, 1, H, d)) return rc;
+    CAPDEC_REQUIRE(dvblk && dbias_part && dk && dv && dbias && aligned16(dvblk) && aligned16(dbias_part) && aligned16(dk) &&
+                       aligned16(dv) && aligned16(dbias) && lddk % 4 == 0 && lddv % 4 == 0 && lddk >= d && lddv >= d &&
+                       (d / H) % 4 == 0,
+                   "capdec_cross1_gather: operands must be non-null, 16-byte aligned, ld %% 4 == 0, ld >= d, head dim %% 4 == 0");
+    const size_t total = (size_t)B * (d / 4);
+    hipLaunchKernelGGL(cross1_gather_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, (hipStream_t)stream,
+                       (const float*)dvblk, (const float*)dbias_part, (float*)dk, lddk, (float*)dv, lddv, (float*)dbias, B, H, d);
+    return check_launch("capdec_cross1_gather");
 }

@@ -57,16 +57,6 @@ S_EMBED, S_PROJ, S_HEAD = 1000, 1001, 1002
 # ---------------------------------------------------------------------------------------------
 # decoder layer
 # ---------------------------------------------------------------------------------------------
-_EYES = {}
-
-
-def _eye(H, device):
-    key = (H, device)
-    if key not in _EYES:
-        _EYES[key] = torch.eye(H, dtype=torch.float32, device=device)
-    return _EYES[key]
-
-
 def _single_key_fast(S, d, H):
     """The streaming single-key cross-attention branch (capdec_cross1_*) covers d % 64 == 0 and power-of-two heads."""
     return S == 1 and d % 64 == 0 and H in (1, 2, 4, 8, 16)
@@ -112,7 +102,7 @@ def layer_fwd(P, x, mem, B, T, S, H, causal, dp, l, save, kv=None):
         # projection cannot reach the output, its gradient is exactly zero) and head h's context is v[b, h-slice]
         # for every token, kept or dropped by the probability dropout.  The out-projection therefore runs on
         # B*H rows (v masked to one head per row) and a streaming kernel assembles the [B*T, d] branch output.
-        vblk = (kv[:, d:].reshape(B, 1, H, d // H) * _eye(H, x.device).view(1, H, H, 1)).reshape(B * H, d)
+        vblk = ops.cross1_spread(kv[:, d:], B, H)
         U = ops.linear_fwd(vblk, P["multihead_attn.out_proj.weight"])
         s2 = ops.cross1_fwd(U, P["multihead_attn.out_proj.bias"], x1, B, T, H, p, dp.seed(sid + S_CA_P), p,
                             dp.seed(sid + S_CA_OUT))
@@ -169,13 +159,11 @@ def layer_bwd(P, G, sv, dx3, mem, dmem, B, T, S, H, causal, dp, l, dkv=None):
     if _single_key_fast(S, d, H):  # see layer_fwd: everything of the branch lives on B*H rows
         dU, dbp = ops.cross1_bwd(g2m, B, T, H, p, dp.seed(sid + S_CA_P))
         ops.linear_wgrad(dU, sv["vblk"], dw=G["multihead_attn.out_proj.weight"])
-        torch.sum(dbp, dim=0, out=G["multihead_attn.out_proj.bias"])
         dvblk = ops.linear_dgrad(dU, P["multihead_attn.out_proj.weight"])  # [B*H, d]; head h's slice of row (b, h) is dv
-        dv = torch.diagonal(dvblk.view(B, H, H, d // H), dim1=1, dim2=2).permute(0, 2, 1).reshape(B, d)
         if not batched:
             dkv = torch.empty_like(kv)
-        dkv[:, :d].zero_()      # dk == 0 exactly (p = 1 for the only key), as torch computes it
-        dkv[:, d:].copy_(dv)
+        # dk == 0 exactly (p = 1 for the only key), as torch computes it; dv = the head-diagonal of dvblk; bias gradient
+        ops.cross1_gather(dvblk, dbp, dkv[:, :d], dkv[:, d:], G["multihead_attn.out_proj.bias"], B, H)
         gw[:d].zero_()          # dq == 0 exactly: zero query-projection gradients, nothing flows to x1 through q
         gb[:d].zero_()
     else:

@@ -567,6 +567,24 @@ def cross1_bwd(g, B, T, H, attn_p=0.0, attn_seed=0):
     return dU, dbp
 
 
+def cross1_spread(v, B, H):
+    """vblk [B*H, d]: row (b, h) = v[b] inside head h's slice, zero elsewhere (v: a [B, d] row-strided fp32 view)."""
+    _mat(v, "cross1_spread.v")
+    d = v.shape[1]
+    vblk = torch.empty((B * H, d), dtype=torch.float32, device=v.device)
+    check(lib().capdec_cross1_spread(ptr(v), v.stride(0), ptr(vblk), B, H, d, stream()), "capdec_cross1_spread")
+    return vblk
+
+
+def cross1_gather(dvblk, dbias_part, dk, dv, dbias, B, H):
+    """dk = 0, dv[b, j] = dvblk[(b, head of j), j], dbias = column sums of dbias_part (see capdec_cross1_gather)."""
+    d = dvblk.shape[1]
+    _mat(dk, "cross1_gather.dk"), _mat(dv, "cross1_gather.dv")
+    check(lib().capdec_cross1_gather(ptr(_req(dvblk, "cross1_gather.dvblk")), ptr(_req(dbias_part, "cross1_gather.dbias_part")),
+                                     ptr(dk), dk.stride(0), ptr(dv), dv.stride(0), ptr(_req(dbias, "cross1_gather.dbias")),
+                                     B, H, d, stream()), "capdec_cross1_gather")
+
+
 def attn_fwd(q, k, v, B, H, Tq, Tk, causal, drop_p=0.0, seed=0, out=None, save_lse=True):
     """q [B*Tq, >=H*dh] / k, v [B*Tk, ...] row-strided 2-D views; returns o [B*Tq, H*dh], lse [B,H,Tq].
     bf16 ``k`` / ``v`` (both, Tk > 1; views of a block a GEMM wrote as bf16) go through capdec_attn_fwd_kv16.

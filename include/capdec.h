@@ -326,6 +326,14 @@ int capdec_cross1_fwd(const void* U, const void* bias, const void* addend, void*
                       float attn_p, uint64_t attn_seed, float out_p, uint64_t out_seed, capdec_stream_t stream);
 int capdec_cross1_bwd(const void* g, void* dU, void* dbias_part, int B, int T, int H, int d, float attn_p,
                       uint64_t attn_seed, capdec_stream_t stream);
+/* The two reshapes around the B*H-row products of that branch (same reference lines):
+ *   capdec_cross1_spread: vblk[b*H+h, j] = v[b*ldv + j] inside head h's slice, 0 elsewhere -- the operand of the U product;
+ *   capdec_cross1_gather: dk[b,:] = 0 (exactly, as torch computes it: the softmax over one key has no gradient),
+ *                         dv[b,j] = dvblk[b*H + head(j), j], dbias[j] = sum_b dbias_part[b,j] (image order: reproducible).
+ * vblk / dvblk / dbias_part dense (ld = d); v, dk, dv row-strided (ld % 4 == 0); head dim % 4 == 0. */
+int capdec_cross1_spread(const void* v, int ldv, void* vblk, int B, int H, int d, capdec_stream_t stream);
+int capdec_cross1_gather(const void* dvblk, const void* dbias_part, void* dk, int lddk, void* dv, int lddv, void* dbias,
+                         int B, int H, int d, capdec_stream_t stream);
 
 /* ---- KV-cached decode step: greedy / beam search (NEW capability: the reference only samples,
  * ref train.py:338-368, and re-runs the whole prefix every step, train.py:312-332) ----------------

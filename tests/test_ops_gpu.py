@@ -671,3 +671,24 @@ def test_double_layernorm_with_broadcast_add_is_bit_identical_to_three_launches(
     check(lib().capdec_layernorm2_fwd(ptr(x), ptr(g1), ptr(b1), ptr(u), W, ptr(g2), ptr(b2), ptr(y), M, d, 1e-5, stream()),
           "capdec_layernorm2_fwd")
     assert torch.equal(y, want)
+
+
+@pytest.mark.parametrize("B,H,d", [(3, 8, 512), (5, 2, 64), (2, 1, 128)])
+def test_cross1_spread_and_gather_equal_the_torch_reshapes(B, H, d):
+    """capdec_cross1_spread / _gather against the torch expressions they replaced on the single-key branch
+    (mask by head with an identity, head-diagonal of the [B*H, d] gradient, exact zeros for dk, column sums)."""
+    from imagecaption_amd import ops
+    g = torch.Generator().manual_seed(B * 100 + H)
+    dh = d // H
+    kv = torch.randn(B, 2 * d, generator=g).to(DEV)
+    v = kv[:, d:]  # a row-strided view, as the engine passes it
+    want = (v.reshape(B, 1, H, dh) * torch.eye(H, device=DEV).view(1, H, H, 1)).reshape(B * H, d)
+    assert torch.equal(ops.cross1_spread(v, B, H), want)
+    dvblk = torch.randn(B * H, d, generator=g).to(DEV)
+    dbp = torch.randn(B, d, generator=g).to(DEV)
+    dkv = torch.full((B, 2 * d), 7.0, device=DEV)
+    dbias = torch.empty(d, device=DEV)
+    ops.cross1_gather(dvblk, dbp, dkv[:, :d], dkv[:, d:], dbias, B, H)
+    dv = torch.diagonal(dvblk.view(B, H, H, dh), dim1=1, dim2=2).permute(0, 2, 1).reshape(B, d)
+    assert torch.all(dkv[:, :d] == 0) and torch.equal(dkv[:, d:], dv)
+    assert relerr(dbias, dbp.double().sum(0)) < 1e-6

@@ -534,6 +534,7 @@ def main():
     modes = {}
     if args.dtype == "fp32" and not args.no_modes and world == 1:
         for mode in [m for m in args.modes.split(",") if m]:
+            torch.cuda.empty_cache()  # fresh segments, as a run of its own would have (see run_leg)
             torch.manual_seed(42)
             m2 = ImageCaptioningModel(cfg["vocab"], cfg["d"], cfg["heads"], cfg["layers"], feature_dim=cfg["din"]).to(dev)
             m2.train()
@@ -549,7 +550,6 @@ def main():
                                           "bf16s": "bf16 storage of every matrix-product and attention operand (the C3 "
                                                    "leg's mode), fp32 accumulate / norms / loss / master weights / optimizer"}[mode]}
             del t2, m2
-            torch.cuda.empty_cache()  # the next mode starts from fresh segments, as a run of its own would
     # the other BASELINE configurations, timed by the same harness in the same run (N = 1 only, like cpu_baseline)
     legs = {}
     if args.config == "c2" and args.dtype == "fp32" and not args.no_legs and world == 1:

@@ -188,6 +188,40 @@ __device__ __forceinline__ void mma_trimg_acc(f32x16* out, const unsigned char* 
         }
     }
 }
+// the same transposed fragments kept in registers (frag[dt][m]) for an image that does not change during a kernel
+template <int DH>
+__device__ __forceinline__ void read_trimg(bf16x8a (*frag)[2], const unsigned char* img, const int* toff) {
+    using L = Img<DH>;
+    constexpr int NDT = DH / 32;
+    const unsigned base = lds_addr(img);
+#pragma unroll
+    for (int m = 0; m < 2; ++m) {
+        s16x4a lo[NDT], hi[NDT];
+#pragma unroll
+        for (int dt = 0; dt < NDT; ++dt) {
+            lo[dt] = lds_read_tr16(base + m * 16 * L::ROWB + (toff[0] ^ (dt << 6)));
+            hi[dt] = lds_read_tr16(base + m * 16 * L::ROWB + (toff[1] ^ (dt << 6)));
+        }
+        if constexpr (NDT == 4)
+            asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(lo[0]), "+v"(hi[0]), "+v"(lo[1]), "+v"(hi[1]), "+v"(lo[2]), "+v"(hi[2]),
+                         "+v"(lo[3]), "+v"(hi[3]));
+        else
+            asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(lo[0]), "+v"(hi[0]), "+v"(lo[1]), "+v"(hi[1]));
+#pragma unroll
+        for (int dt = 0; dt < NDT; ++dt) {
+            const s16x8a v = {lo[dt][0], lo[dt][1], lo[dt][2], lo[dt][3], hi[dt][0], hi[dt][1], hi[dt][2], hi[dt][3]};
+            frag[dt][m] = __builtin_bit_cast(bf16x8a, v);
+        }
+    }
+}
+template <int DH>
+__device__ __forceinline__ void mma_trfrag_acc(f32x16* out, const bf16x8a (*frag)[2], const bf16x8a* bfrag) {
+#pragma unroll
+    for (int m = 0; m < 2; ++m)
+#pragma unroll
+        for (int dt = 0; dt < DH / 32; ++dt)
+            out[dt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(frag[dt][m], bfrag[m], out[dt], 0, 0, 0);
+}
 // accumulator-layout values x[16] -> the two B fragments (k = accumulator row, 16 per fragment)
 __device__ __forceinline__ void pack_rows(bf16x8a* f, const float* x) {
 #pragma unroll
@@ -510,18 +544,19 @@ __global__ __launch_bounds__(64) void attn16_bwd_dkv_kernel(Attn16Params p) {
 // Backward when all queries of a (b, h) fit one tile (Tq <= 32: the training shapes C2 / C3): ONE wave per (b, h) walks
 // the key tiles once and produces dQ, dK and dV together -- K and V are read once (the two-kernel form reads them
 // twice, and its dK/dV waves re-read Q and dO once per key tile), dK / dV of a tile are complete when the tile is
-// done.  Q and dO stay in LDS for the whole walk (their transposes feed dK^T += Q^T dS, dV^T += dO^T Pd) and in
-// registers in fragment form; the scores are computed in both orientations from one read of the K / V fragments
+// done.  dO stays in LDS for the whole walk and Q in registers (row fragments and their transposes: dK^T += Q^T dS,
+// dV^T += dO^T Pd); the scores are computed in both orientations from one read of the K / V fragments
 // (query on the lanes for dQ, key on the lanes for dK / dV): 16 extra MFMAs per tile instead of moving P between lanes.
 template <int DH>
 __global__ __launch_bounds__(64) void attn16_bwd_fused_kernel(Attn16Params p) {
     using L = Img<DH>;
     constexpr int NST = L::NST, NI = L::NI;
-    __shared__ __attribute__((aligned(1024))) unsigned char smem[(2 + NST * 2) * L::BYTES];
-    __shared__ float line[32];
-    unsigned char* Qs = smem;
-    unsigned char* dOs = smem + L::BYTES;
-    unsigned char* ring = smem + 2 * L::BYTES;
+    // dO image + the K / V ring: 40 KB (dh 128) / 36 KB (dh 64), four workgroups per CU.  Q passes through the last
+    // ring slot's V image once, on its way into registers (row fragments and their transposes).
+    __shared__ __attribute__((aligned(1024))) unsigned char smem[(1 + NST * 2) * L::BYTES];
+    unsigned char* dOs = smem;
+    unsigned char* ring = smem + L::BYTES;
+    unsigned char* Qs = ring + (NST - 1) * 2 * L::BYTES + L::BYTES;
     const int lane = threadIdx.x, l31 = lane & 31, half = lane >> 5;
     int bh, qt;
     attn_item(p.B * p.H, 1, false, bh, qt);
@@ -547,7 +582,7 @@ __global__ __launch_bounds__(64) void attn16_bwd_fused_kernel(Attn16Params p) {
     dma_image<DH>(Qs, p.q + (size_t)b * p.Tq * p.ldq + h * DH, p.ldq, 0, p.Tq, lane);
     dma_image<DH>(dOs, p.dout + (size_t)b * p.Tq * p.lddo + h * DH, p.lddo, 0, p.Tq, lane);
 #pragma unroll
-    for (int s = 0; s < NST; ++s) {
+    for (int s = 0; s < NST - 1; ++s) {
         if (s < nkt) {
             dma_image<DH>(ring + s * 2 * L::BYTES, kg, p.ldk, s * 32, p.Tk, lane);
             dma_image<DH>(ring + s * 2 * L::BYTES + L::BYTES, vg, p.ldv, s * 32, p.Tk, lane);
@@ -556,12 +591,18 @@ __global__ __launch_bounds__(64) void attn16_bwd_fused_kernel(Attn16Params p) {
     const int foff = frag_off<DH>(l31, half);
     int toff[2];
     tr_offs<DH>(lane, toff);
-    wait_images<NI>(2 * max(min(nkt, NST) - 1, 0));  // Q, dO and the first key tile have landed
-    bf16x8a qf[DH / 16], dof[DH / 16];
+    wait_images<NI>(2 * max(min(nkt, NST - 1) - 1, 0));  // Q, dO and the first key tile have landed
+    bf16x8a qf[DH / 16], dof[DH / 16], qT[DH / 32][2];
 #pragma unroll
     for (int ks = 0; ks < DH / 16; ++ks) {
         qf[ks] = *reinterpret_cast<const bf16x8a*>(Qs + (foff ^ (ks << 5)));
         dof[ks] = *reinterpret_cast<const bf16x8a*>(dOs + (foff ^ (ks << 5)));
+    }
+    read_trimg<DH>(qT, Qs, toff);
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");  // Q is in registers: its slot joins the ring
+    if (NST - 1 < nkt) {
+        dma_image<DH>(ring + (NST - 1) * 2 * L::BYTES, kg, p.ldk, (NST - 1) * 32, p.Tk, lane);
+        dma_image<DH>(ring + (NST - 1) * 2 * L::BYTES + L::BYTES, vg, p.ldv, (NST - 1) * 32, p.Tk, lane);
     }
     float dsum = 0.f;
 #pragma unroll
@@ -569,13 +610,9 @@ __global__ __launch_bounds__(64) void attn16_bwd_fused_kernel(Attn16Params p) {
 #pragma unroll
         for (int e = 0; e < 8; ++e) dsum = __fmaf_rn((float)dof[ks][e], (float)of[ks][e], dsum);
     dsum += __shfl_xor(dsum, 32, 64);
-    if (lane < 32) {
-        line[lane] = dsum;
-        if (query < p.Tq) p.delta[(size_t)bh * p.Tq + query] = dsum;
-    }
-    __syncthreads();
+    if (lane < 32 && query < p.Tq) p.delta[(size_t)bh * p.Tq + query] = dsum;
 #pragma unroll
-    for (int r = 0; r < 16; ++r) da[r] = line[row_of(r, half)];
+    for (int r = 0; r < 16; ++r) da[r] = __shfl(dsum, row_of(r, half), 64);  // per-query value -> accumulator-row order
 
     f32x16 dqacc[DH / 32];
 #pragma unroll
@@ -632,7 +669,7 @@ __global__ __launch_bounds__(64) void attn16_bwd_fused_kernel(Attn16Params p) {
 #pragma unroll
                 for (int r = 0; r < 16; ++r) dkacc[dt][r] = dvacc[dt][r] = 0.f;
             mma_trimg_acc<DH>(dvacc, dOs, toff, pb);
-            mma_trimg_acc<DH>(dkacc, Qs, toff, sb);
+            mma_trfrag_acc<DH>(dkacc, qT, sb);
             // The NEXT tile is awaited here, BEFORE this tile's stores are issued: loads and stores retire through one
             // in-order counter, so a wait placed after the stores would also wait for their acknowledgements (a
             // store round trip per tile: 211 -> 172 us was all the one-walk form gained with the wait at the top).

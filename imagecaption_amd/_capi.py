@@ -24,6 +24,13 @@ class Epilogue(C.Structure):
                 ("c16", _vp), ("ldc16", _i)]
 
 
+class CastDesc(C.Structure):
+    _fields_ = [("src", _vp), ("dst", _vp), ("lds", _i), ("ldd", _i), ("R", _i), ("C", _i),
+                ("vec", _i), ("first_block", _i), ("blocks", _i), ("reserved", _i)]
+
+
+CAST_MULTI_MAX = 256
+
 # name -> (restype, argtypes); mirrors include/capdec.h one to one
 SIGNATURES = {
     "capdec_abi_version": (_i, []),
@@ -68,6 +75,8 @@ SIGNATURES = {
     "capdec_ce_finalize": (_i, [_vp, _i, _vp, _i, _vp, _vp, _vp, _i, _i, _f, _vp]),
     "capdec_ce_dlogits": (_i, [_vp, _i, _vp, _vp, _i, _i, _f, _f, _vp]),
     "capdec_cast_bf16": (_i, [_vp, _i, _vp, _i, _i, _i, _vp]),
+    "capdec_cast_bf16_multi_plan": (_i, [C.POINTER(CastDesc), _i, _vp, C.POINTER(_i)]),
+    "capdec_cast_bf16_multi": (_i, [_vp, _i, _i, _vp]),
     "capdec_ce_dlogits_bf16": (_i, [_vp, _i, _vp, _vp, _i, _i, _f, _f, _vp, _i, _vp]),
     "capdec_reduce_workspace_bytes": (_sz, []),
     "capdec_sum": (_i, [_vp, _sz, _f, _vp, _vp, _sz, _vp]),

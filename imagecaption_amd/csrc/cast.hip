@@ -4,6 +4,8 @@
 // zeros.  HBM-bound streaming kernels: 32 B in, 16 B out per thread step; round-to-nearest-even (the hardware's
 // v_cvt_pk_bf16_f32).
 //   capdec_cast_bf16        plain copy
+//   capdec_cast_bf16_multi  the same copy of MANY matrices in one launch (every weight operand of a training step:
+//                           40 launches of a few microseconds each become one), over a table planned once
 //   capdec_ce_dlogits_bf16  the label-smoothed cross-entropy gradient of a logits block, written straight to its
 //                           bf16 copy (ref train.py:41-50 backward): the fp32 dlogits matrix is never materialised
 #include "common.h"
@@ -34,6 +36,27 @@ __global__ __launch_bounds__(256) void cast_bf16_kernel(const float* __restrict_
 #pragma unroll
         for (int e = 0; e < 8; ++e) o[e] = (__bf16)v[e];
         *reinterpret_cast<bf16x8c*>(dst + (size_t)r * ldd + c0) = o;
+    }
+}
+
+// many matrices, one launch: workgroup b belongs to the table entry whose [first_block, first_block + blocks) holds b
+// (a uniform scan over at most CAPDEC_CAST_MULTI_MAX entries) and walks that matrix with its entry's workgroups
+__global__ __launch_bounds__(256) void cast_bf16_multi_kernel(const capdec_cast_desc* __restrict__ table, int n) {
+    int t = 0;
+    while (t + 1 < n && table[t + 1].first_block <= (int)blockIdx.x) ++t;
+    const capdec_cast_desc d = table[t];
+    const float* src = (const float*)d.src;
+    __bf16* dst = (__bf16*)d.dst;
+    const int c8 = d.ldd / 8;
+    const size_t total = (size_t)d.R * c8;
+    for (size_t g = (size_t)((int)blockIdx.x - d.first_block) * 256 + threadIdx.x; g < total; g += (size_t)d.blocks * 256) {
+        const int r = (int)(g / c8), c0 = (int)(g % c8) * 8;
+        float v[8];
+        load8(src + (size_t)r * d.lds + c0, c0, d.C, d.vec != 0, v);
+        bf16x8c o;
+#pragma unroll
+        for (int e = 0; e < 8; ++e) o[e] = (__bf16)v[e];
+        *reinterpret_cast<bf16x8c*>(dst + (size_t)r * d.ldd + c0) = o;
     }
 }
 
@@ -75,6 +98,41 @@ extern "C" int capdec_cast_bf16(const void* src, int lds, void* dst, int ldd, in
     hipLaunchKernelGGL(cast_bf16_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, (const float*)src, lds,
                        (__bf16*)dst, ldd, R, C, vec);
     return check_launch("capdec_cast_bf16");
+}
+
+extern "C" int capdec_cast_bf16_multi_plan(capdec_cast_desc* descs, int n, void* table_dev, int* total_blocks) {
+    CAPDEC_REQUIRE(descs && table_dev && total_blocks && n > 0 && n <= CAPDEC_CAST_MULTI_MAX,
+                   "capdec_cast_bf16_multi_plan: bad arguments (n=%d, at most %d matrices per table)", n, CAPDEC_CAST_MULTI_MAX);
+    int first = 0;
+    for (int i = 0; i < n; ++i) {
+        capdec_cast_desc& d = descs[i];
+        CAPDEC_REQUIRE(d.src && d.dst && d.R > 0 && d.C > 0 && d.lds >= d.C, "capdec_cast_bf16_multi_plan: matrix %d: bad R=%d C=%d lds=%d",
+                       i, d.R, d.C, d.lds);
+        CAPDEC_REQUIRE(d.ldd % 8 == 0 && d.ldd >= d.C && aligned16(d.dst),
+                       "capdec_cast_bf16_multi_plan: matrix %d: ldd=%d must be a multiple of 8 that covers the row, dst 16-byte aligned",
+                       i, d.ldd);
+        const size_t groups = (size_t)d.R * (d.ldd / 8);
+        size_t blocks = (groups + 1023) / 1024;  // four 8-element groups per thread
+        if (blocks > 4096) blocks = 4096;
+        d.vec = aligned16(d.src) && d.lds % 4 == 0;
+        d.first_block = first;
+        d.blocks = (int)blocks;
+        first += (int)blocks;
+    }
+    *total_blocks = first;
+    if (hipMemcpy(table_dev, descs, (size_t)n * sizeof(capdec_cast_desc), hipMemcpyHostToDevice) != hipSuccess) {
+        set_error("capdec_cast_bf16_multi_plan: copying the table to the device failed");
+        return CAPDEC_ERR_LAUNCH;
+    }
+    return 0;
+}
+
+extern "C" int capdec_cast_bf16_multi(const void* table_dev, int n, int total_blocks, capdec_stream_t stream) {
+    CAPDEC_REQUIRE(table_dev && n > 0 && n <= CAPDEC_CAST_MULTI_MAX && total_blocks > 0,
+                   "capdec_cast_bf16_multi: bad arguments (n=%d, total_blocks=%d)", n, total_blocks);
+    hipLaunchKernelGGL(cast_bf16_multi_kernel, dim3((unsigned)total_blocks), dim3(256), 0, (hipStream_t)stream,
+                       (const capdec_cast_desc*)table_dev, n);
+    return check_launch("capdec_cast_bf16_multi");
 }
 
 extern "C" int capdec_ce_dlogits_bf16(const void* logits, int ldl, const void* lse, const int64_t* targets, int M, int V,

@@ -71,6 +71,42 @@ def _bf16_operand(t, name):
     return hit[1]
 
 
+class Bf16Copies:
+    """bf16 copies of a fixed set of fp32 matrices (a trainer's weight operands: same addresses every step), all
+    refreshed by ONE launch (capdec_cast_bf16_multi).  ``sources`` are 2-D fp32 views; ``copies`` may bring the
+    destination views to adopt (what ``cast_bf16`` returned for them), else they are allocated here."""
+
+    def __init__(self, sources, copies=None):
+        import ctypes as C
+        if not 0 < len(sources) <= _capi.CAST_MULTI_MAX:
+            raise _capi.CapdecError(f"Bf16Copies: 1 .. {_capi.CAST_MULTI_MAX} matrices per table, got {len(sources)}")
+        self.sources = list(sources)
+        for t in self.sources:
+            _mat(t, "Bf16Copies.src")
+        if copies is None:
+            copies = [torch.empty((t.shape[0], _bf16_pitch(t.shape[1])), dtype=torch.bfloat16, device=t.device)[:, :t.shape[1]]
+                      for t in self.sources]
+        self.copies = list(copies)
+        descs = (_capi.CastDesc * len(self.sources))()
+        for d, t, c in zip(descs, self.sources, self.copies):
+            if c.dtype != torch.bfloat16 or tuple(c.shape) != tuple(t.shape) or c.stride(1) != 1 or c.device != t.device:
+                raise _capi.CapdecError(f"Bf16Copies: copy {tuple(c.shape)} / {c.dtype} does not fit source {tuple(t.shape)}")
+            d.src, d.dst, d.lds, d.ldd, d.R, d.C = ptr(t), ptr(c), t.stride(0), c.stride(0), t.shape[0], t.shape[1]
+        self.table = torch.empty(C.sizeof(descs), dtype=torch.uint8, device=self.sources[0].device)
+        total = C.c_int(0)
+        check(lib().capdec_cast_bf16_multi_plan(descs, len(self.sources), ptr(self.table), C.byref(total)),
+              "capdec_cast_bf16_multi_plan")
+        self.total_blocks = total.value
+
+    def refresh(self):
+        check(lib().capdec_cast_bf16_multi(ptr(self.table), len(self.sources), self.total_blocks, stream()),
+              "capdec_cast_bf16_multi")
+
+    def memo(self):
+        """The BF16_MEMO entries of these matrices (valid until a source changes: call refresh() first)."""
+        return {(t.data_ptr(), t.shape[0], t.shape[1], t.stride(0)): (t, c) for t, c in zip(self.sources, self.copies)}
+
+
 class compute_dtype:
     """with ops.compute_dtype("bf16"): ...  -- scoped override of COMPUTE_DTYPE."""
 

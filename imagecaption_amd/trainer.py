@@ -93,6 +93,9 @@ class CaptionTrainer:
         self.gnorm_sq = torch.zeros(1, dtype=torch.float32, device=dev)
         self.reducer = BucketReducer(self.flat_g, self.bucket_ranges, process_group, overlap)
         self._logits = self._ce_part = self._embed_ws = None
+        # bf16 storage: the weight operands' copies, refreshed by one launch per step (ops.Bf16Copies) unless switched
+        # off (then each weight is cast by the first product of the step that reads it: same values, ~40 launches)
+        self._w16, self.one_launch_weight_casts = None, True
         self.side = ops.SideStream(dev) if (side_stream_wgrad and dev.type == "cuda") else None
         self._rows = None  # B*T of the first step; data-parallel ranks must all run this many rows (1/(rows*world))
         if self.world > 1:
@@ -144,8 +147,20 @@ class CaptionTrainer:
         # input-gradient and weight-gradient products that read it; dropped when the step's kernels are enqueued
         memo, ops.BF16_MEMO = ops.BF16_MEMO, ({} if self.dtype == "bf16s" else None)
         try:
+            if self._w16 is not None and self.dtype == "bf16s" and self.one_launch_weight_casts:
+                self._w16.refresh()
+                ops.BF16_MEMO.update(self._w16.memo())
             with ops.compute_dtype(self.dtype):
-                return self._forward_backward(features, captions, train, keep_logits)
+                out = self._forward_backward(features, captions, train, keep_logits)
+            if self._w16 is None and self.dtype == "bf16s" and self.one_launch_weight_casts:
+                # the first step cast each weight operand on first use; every later step refreshes those same copies
+                # with one launch up front.  Weight operands are recognised by their storage: views of the flat block
+                base = self.flat_p.untyped_storage().data_ptr()
+                w = [(t, c) for t, c in ops.BF16_MEMO.values()
+                     if t.dtype == torch.float32 and t.untyped_storage().data_ptr() == base]
+                if w:
+                    self._w16 = ops.Bf16Copies([t for t, _ in w], [c for _, c in w])
+            return out
         finally:
             if self.side is not None:
                 self.side.join()

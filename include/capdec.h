@@ -128,6 +128,21 @@ int capdec_gemm(int transA, int transB, int M, int N, int K, const void* A, int 
  * block [M, V] written directly as its bf16 copy: dst[m][v] = bf16(grad_scale * (exp(z - lse[m]) - eps/V -
  * (1 - eps) * [v == targets[m]])), padding columns zero; lse from capdec_ce_finalize. */
 int capdec_cast_bf16(const void* src, int lds, void* dst, int ldd, int R, int C, capdec_stream_t stream);
+/* capdec_cast_bf16_multi: capdec_cast_bf16 of up to CAPDEC_CAST_MULTI_MAX matrices in ONE launch -- every weight
+ * operand of a training step (the casts autocast would make per F.linear call, see above), whose addresses do not
+ * change from step to step.  capdec_cast_bf16_multi_plan checks the matrices (src, dst, lds, ldd, R, C as for
+ * capdec_cast_bf16; the other fields are filled in here), writes the table to table_dev (n * sizeof(capdec_cast_desc)
+ * bytes of device memory, a blocking copy: call it once, not per step) and returns the launch size in *total_blocks;
+ * capdec_cast_bf16_multi(table_dev, n, total_blocks) then makes all the copies, bit-identical to n single calls. */
+#define CAPDEC_CAST_MULTI_MAX 256
+typedef struct capdec_cast_desc {
+    const void* src; /* fp32 [R, C], row stride lds */
+    void* dst;       /* bf16 [R, ldd] */
+    int lds, ldd, R, C;
+    int vec, first_block, blocks, reserved; /* filled in by capdec_cast_bf16_multi_plan */
+} capdec_cast_desc;
+int capdec_cast_bf16_multi_plan(capdec_cast_desc* descs, int n, void* table_dev, int* total_blocks);
+int capdec_cast_bf16_multi(const void* table_dev, int n, int total_blocks, capdec_stream_t stream);
 int capdec_ce_dlogits_bf16(const void* logits, int ldl, const void* lse, const int64_t* targets, int M, int V,
                            float eps, float grad_scale, void* dst, int ldd, capdec_stream_t stream);
 

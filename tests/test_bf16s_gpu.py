@@ -49,6 +49,35 @@ def test_cast_is_round_to_nearest_even_with_zero_padding(R, C, pad):
     assert torch.all(whole[:, C:] == 0)
 
 
+def test_one_launch_cast_of_many_matrices_equals_the_single_casts():
+    ops = _ops()
+    g = torch.Generator().manual_seed(77)
+    shapes = [(1, 1), (3, 7), (33, 100), (512, 512), (257, 1024), (2048, 512), (64, 30001), (10000, 512), (5, 8)]
+    block = torch.randn(sum(r * c for r, c in shapes) + 3, generator=g).to(DEV) * 3
+    srcs, off = [], 3  # views of one flat block at odd offsets, as a trainer's weights are (some not 16-byte aligned)
+    for r, c in shapes:
+        srcs.append(block[off:off + r * c].view(r, c))
+        off += r * c
+    srcs.append(srcs[3][:256])       # a slice of a weight (the cross-attention query rows)
+    srcs.append(srcs[4][:, :1000])   # a row-strided view
+    copies = ops.Bf16Copies(srcs)
+    for _ in range(2):  # the second refresh follows a change of the sources
+        copies.refresh()
+        for t, c in zip(srcs, copies.copies):
+            one = ops.cast_bf16(t)
+            assert c.stride(0) == one.stride(0) and torch.equal(c, one)
+            ldd = c.stride(0)
+            assert torch.all(torch.as_strided(c, (t.shape[0], ldd), (ldd, 1))[:, t.shape[1]:] == 0)
+        block.mul_(-1.7)
+    memo = copies.memo()
+    assert len(memo) == len(srcs) and all(v[1] is c for v, c in zip(memo.values(), copies.copies))
+    from imagecaption_amd._capi import CapdecError
+    with pytest.raises(CapdecError):
+        ops.Bf16Copies([])
+    with pytest.raises(CapdecError):
+        ops.Bf16Copies([srcs[0]], [torch.empty(2, 8, dtype=torch.bfloat16, device=DEV)[:, :1]])
+
+
 @pytest.mark.parametrize("M,N,K", [(1, 1, 4), (3, 50, 24), (37, 108, 64), (129, 257, 100), (256, 512, 512),
                                     (300, 1000, 130), (5120, 128, 64), (64, 64, 2048), (70, 70, 5125), (131, 77, 9)])
 @pytest.mark.parametrize("ta,tb", [(0, 1), (0, 0), (1, 0), (1, 1)])

@@ -1,6 +1,7 @@
 """Soak: the C2 training step run N times twice from the same seed must end in bitwise identical parameters (the side
 lane, shared workspaces and batched K/V products leave no room for a race), with a finite, decreasing loss; then
-beam / sampler decode twice -> identical ids."""
+beam / sampler decode twice -> identical ids.  usage: soak.py [steps] [dtype: fp32 | f32x3 | bf16 | bf16s] [config: c2 | c3] [tune]
+(tune: measured GEMM plans, pinned once for both runs -- the plans bench.py times)"""
 import os, sys, time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
@@ -10,15 +11,19 @@ from imagecaption_amd.trainer import CaptionTrainer
 from imagecaption_amd.decode import CaptionDecoder
 
 steps = int(sys.argv[1]) if len(sys.argv) > 1 else 300
-cfg = bench.CONFIGS["c2"]
+dtype = sys.argv[2] if len(sys.argv) > 2 else "fp32"
+cfg = bench.CONFIGS[sys.argv[3] if len(sys.argv) > 3 else "c2"]
 dev = torch.device("cuda")
 f, c = bench.synth_batch(cfg, cfg["batch"], dev, 0)
 
 def run():
     torch.manual_seed(42)
     model = ImageCaptioningModel(cfg["vocab"], cfg["d"], cfg["heads"], cfg["layers"], feature_dim=cfg["din"]).to(dev).train()
-    tr = CaptionTrainer(model, dropout=0.1, seed=42)
+    tr = CaptionTrainer(model, dropout=0.1, seed=42, dtype=dtype)
     losses = []
+    if "tune" in sys.argv[4:] and not run.tuned:
+        tr.tune(f, c)  # plans are process-wide: the second run reuses them
+        run.tuned = True
     for i in range(steps):
         loss = tr.step(f, c)
         if i % 50 == 0 or i == steps - 1:
@@ -26,6 +31,7 @@ def run():
     torch.cuda.synchronize()
     return model, tr.flat_p.clone(), losses
 
+run.tuned = False
 t0 = time.perf_counter()
 m1, p1, l1 = run()
 m2, p2, l2 = run()

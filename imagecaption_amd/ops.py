@@ -195,18 +195,34 @@ class SideStream:
         self.streams = (self.stream,)
         self.keep = []       # tensors the lane still reads; released at join()
         self.pending = False
+        # the hand-over costs host time on every weight gradient (~70 per step, and the bf16-storage step is bound by
+        # its host side): events are reused in rotation (a wait refers to the record that preceded it, so re-recording
+        # an event later is harmless) and the lane is entered by setting torch's current stream directly
+        self._events = [torch.cuda.Event() for _ in range(32)]
+        self._next = 0
+        self._index = self.stream.device_index
+
+    def _current(self):
+        try:  # torch.cuda.current_stream() minus its device-index resolution (most of its cost)
+            sid, idx, typ = torch._C._cuda_getCurrentStream(self._index)
+            return torch.cuda.Stream(stream_id=sid, device_index=idx, device_type=typ)
+        except (AttributeError, TypeError, ValueError):
+            return torch.cuda.current_stream(self._index)
 
     def run(self, fn, *tensors):
         """Enqueue fn() on the lane, ordered after everything enqueued so far on the current stream."""
         global _WS_TAG
-        ev = torch.cuda.Event()
-        ev.record()
+        cur = self._current()
+        ev = self._events[self._next]
+        self._next = (self._next + 1) % len(self._events)
+        ev.record(cur)
         self.stream.wait_event(ev)
         prev, _WS_TAG = _WS_TAG, "side"
+        torch.cuda.set_stream(self.stream)
         try:
-            with torch.cuda.stream(self.stream):
-                fn()
+            fn()
         finally:
+            torch.cuda.set_stream(cur)
             _WS_TAG = prev
         self.keep.extend(tensors)
         self.pending = True

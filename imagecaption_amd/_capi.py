@@ -21,7 +21,7 @@ class Epilogue(C.Structure):
     _fields_ = [("bias", _vp), ("addend", _vp), ("pre", _vp), ("aux", _vp), ("colsum", _vp),
                 ("ld_addend", _i), ("act", _i), ("drop_p", _f), ("drop_seed", _u64),
                 ("ce_partials", _vp), ("ce_lse", _vp), ("ce_targets", _vp), ("ce_eps", _f), ("ce_grad_scale", _f),
-                ("c16", _vp), ("ldc16", _i)]
+                ("c16", _vp), ("ldc16", _i), ("bf16_unpadded", _i)]
 
 
 class CastDesc(C.Structure):

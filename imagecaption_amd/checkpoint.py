@@ -20,6 +20,14 @@ Files are read with ``torch.load(..., weights_only=True)`` only: nothing in a ch
 The reference's ``metrics`` dict holds ``np.mean(...)`` results (ref train.py:251-264 -> numpy.float64), which
 pickle through ``numpy._core.multiarray.scalar`` + a dtype class; those data constructors (and nothing else)
 are allow-listed for the load.  A file the safe loader still refuses is reported, not force-loaded.
+
+One such refusal is expected and is the right failure: torch keys its allow-list by a constructor's own
+``__module__.__qualname__``, so under numpy >= 2 the list holds ``numpy._core.multiarray.scalar``; a checkpoint
+whose metrics were pickled under numpy 1.x names ``numpy.core.multiarray.scalar`` and is REFUSED here (loudly, with
+the loader's message) -- re-save it with plain floats, or load it under the numpy it was written with.  The old
+spelling is deliberately not aliased into the list.  After a load every numpy scalar found in the file must be of a
+numeric kind (float / int / unsigned / bool); anything else (object, structured, string dtypes, which ``numpy.dtype``
+in the allow-list could in principle describe) is rejected.
 """
 import numpy as np
 import torch
@@ -38,6 +46,21 @@ def _numpy_scalar_globals():
         scalar = np.core.multiarray.scalar
     kinds = ("float64", "float32", "float16", "int64", "int32", "int16", "int8", "uint8", "bool")
     return [scalar, np.dtype] + sorted({type(np.dtype(k)) for k in kinds}, key=lambda c: c.__name__)
+
+
+def _require_numeric_scalars(obj, path, where="checkpoint"):
+    """Every numpy scalar / dtype reachable in a loaded checkpoint must be of a numeric kind."""
+    if isinstance(obj, dict):
+        for k, v in obj.items():
+            _require_numeric_scalars(v, path, f"{where}[{k!r}]")
+    elif isinstance(obj, (list, tuple)):
+        for i, v in enumerate(obj):
+            _require_numeric_scalars(v, path, f"{where}[{i}]")
+    elif isinstance(obj, (np.generic, np.ndarray, np.dtype)):
+        dt = obj if isinstance(obj, np.dtype) else obj.dtype
+        if dt.kind not in "fiub":
+            raise RuntimeError(f"{path}: {where} is a numpy value of dtype {dt} (kind {dt.kind!r}); only numeric numpy "
+                               "scalars are accepted in a checkpoint")
 
 
 def split_state_dict(sd):
@@ -76,6 +99,7 @@ def load_reference_checkpoint(path, model, optimizer=None, scheduler=None, map_l
         raise RuntimeError(f"{path}: torch.load(weights_only=True) refused this file ({e}); it is not loaded") from e
     if "model_state_dict" not in ckpt:
         raise RuntimeError(f"{path}: no 'model_state_dict' (keys: {sorted(ckpt)})")
+    _require_numeric_scalars(ckpt, path)
     dec, vit = split_state_dict(ckpt["model_state_dict"])
     own = model.state_dict()
     own_dec = {k for k in own if not k.startswith(VIT_PREFIX)}

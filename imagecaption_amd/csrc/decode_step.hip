@@ -24,6 +24,12 @@ extern "C" int capdec_decode_step(const capdec_decode_layer* layers, int L, void
                                   size_t workspace_bytes, void* gemm_workspace, size_t gemm_workspace_bytes,
                                   capdec_stream_t stream) {
     CAPDEC_REQUIRE(layers && L > 0 && x && anc, "capdec_decode_step: null pointer");
+    // every matrix of this call is fp32 (activations, weights, cache): the bf16-STORAGE type would make capdec_gemm read
+    // those very pointers as bf16 matrices.  Callers in that mode keep the op-by-op path, whose products cast their
+    // operands (decode.py CaptionDecoder._step).
+    CAPDEC_REQUIRE(dtype == CAPDEC_F32 || dtype == CAPDEC_BF16 || dtype == CAPDEC_F32X3,
+                   "capdec_decode_step: dtype %d -- all operands of this call are fp32 matrices; CAPDEC_BF16S (bf16 "
+                   "storage) is not accepted here", dtype);
     CAPDEC_REQUIRE(R > 0 && H > 0 && d > 0 && d % H == 0 && d % 4 == 0 && dff > 0 && Tmax > 0 && t >= 0 && t < Tmax && W > 0 &&
                        S > 0, "capdec_decode_step: bad geometry R=%d H=%d d=%d dff=%d Tmax=%d t=%d W=%d S=%d", R, H, d, dff,
                    Tmax, t, W, S);
@@ -74,7 +80,10 @@ extern "C" int capdec_decode_step(const capdec_decode_layer* layers, int L, void
         qkv.A = xf; qkv.B = w_in; qkv.C = q; qkv.M = R; qkv.N = 3 * d; qkv.K = d; qkv.lda = d; qkv.ldb = d; qkv.ldc = d;
         qkv.bias = b_in; qkv.drop = make_dropout(0.f, 0);
         qkv.C2 = kv_t; qkv.ldc2 = Tmax * 2 * d; qkv.n_split = d;
-        if (gemm_skinny_ok(qkv, true, true, dtype)) {
+        // (a plan pinned for either of the two products sends the op-by-op path to the tiled kernel: follow it, the
+        // contract is bit-identity with that path)
+        if (gemm_skinny_ok(qkv, true, true, dtype) && !gemm_plan_forced(0, 1, R, d, d, dtype) &&
+            !gemm_plan_forced(0, 1, R, 2 * d, d, dtype)) {
             // few rows: q and k | v as ONE product over the packed in-projection, its columns split between the query
             // buffer and the cache (each output element is computed exactly as by the two separate products)
             STEP(launch_gemm_skinny(qkv, gemm_workspace, gemm_workspace_bytes, st));

@@ -566,13 +566,15 @@ static void launch_pair(const GemmParams& p, bool AKC, bool BKC, dim3 grid, hipS
 }
 
 // The DMA kernel needs: zero padding behind the reduction extent of every k-contiguous operand up to the next
-// multiple of 64 (its pitch says whether the padding exists; capdec_cast_bf16 writes the zeros), and a reduction
-// tail that at least one operand zeroes (two k-major operands have no padding: K must then be a multiple of 64).
+// multiple of 64 (its pitch says whether the padding exists; capdec_cast_bf16 writes the zeros -- a caller whose wide
+// pitch means something else says so with capdec_epilogue.bf16_unpadded), and a reduction tail that at least one
+// operand zeroes (two k-major operands have no padding: K must then be a multiple of 64).
 bool gemm_bf16s_dma_ok(const GemmParams& p, bool AKC, bool BKC) {
     const int k64 = cdiv(p.K, DBK) * DBK;
     if (AKC && p.lda < k64) return false;
     if (BKC && p.ldb < k64) return false;
     if (!AKC && !BKC && p.K % DBK) return false;
+    if (p.K % DBK && ((AKC && (p.unpadded & 1)) || (BKC && (p.unpadded & 2)))) return false;
     // 32-bit element offsets inside each operand
     if ((uint64_t)(AKC ? p.M : p.K) * (uint64_t)p.lda >= (1ull << 31) || (uint64_t)(BKC ? p.N : p.K) * (uint64_t)p.ldb >= (1ull << 31))
         return false;

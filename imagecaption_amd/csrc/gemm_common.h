@@ -30,6 +30,7 @@ struct GemmParams {
     float ce_gs, ce_u, ce_w;  // grad scale, eps / V, 1 - eps
     __bf16* c16;            // if set: the result goes THERE as bf16 (row stride ldc16), not to C
     int ldc16;
+    int unpadded;           // bf16 storage: bit 0 / 1 = A's / B's row padding behind K is NOT known to be zero
     // gemm_skinny.hip only (library-internal, capdec_decode_step): columns n >= n_split go to C2[m, n - n_split]
     // (row stride ldc2) -- one product writes the query block and, through the cache's row stride, the K | V block
     float* C2;
@@ -283,6 +284,7 @@ int launch_gemm_f32x3(const GemmParams& p, const GemmPlan& pl, bool AK, bool BKM
 GemmPlan plan_gemm_bf16s(int M, int N, int K, const GemmForce& force);
 void launch_gemm_bf16s(const GemmParams& p, const GemmPlan& pl, bool AKC, bool BKC, hipStream_t st);  // A, B: bf16
 bool gemm_skinny_ok(const GemmParams& p, bool AK, bool BKM, int dtype);  // few-row decode products (gemm_skinny.hip)
+bool gemm_plan_forced(int ta, int tb, int M, int N, int K, int dtype);   // tuning hook or pinned plan applies (gemm_f32.hip)
 int launch_gemm_skinny(GemmParams p, void* workspace, size_t workspace_bytes, hipStream_t st);  // 0 or CAPDEC_ERR_WORKSPACE
 size_t gemm_skinny_workspace_bytes(int M, int N, int K);
 bool gemm_bf16s_dma_ok(const GemmParams& p, bool AKC, bool BKC);  // operands fit the LDS-DMA kernels (gemm_bf16s_dma.hip)

@@ -37,6 +37,8 @@ static GemmForce resolve_force(int ta, int tb, int M, int N, int K, int dtype) {
     return it == g_plans.end() ? g_gemm_force : it->second;
 }
 
+bool gemm_plan_forced(int ta, int tb, int M, int N, int K, int dtype) { return resolve_force(ta, tb, M, N, K, dtype).bm != 0; }
+
 template <bool VEC>
 __device__ __forceinline__ float4 load4(const float* ptr, bool ok, int rem) {
     float4 r = make_float4(0.f, 0.f, 0.f, 0.f);
@@ -412,7 +414,8 @@ extern "C" void capdec_gemm_plan_clear(void) {
 extern "C" size_t capdec_gemm_workspace_bytes(int M, int N, int K) {
     if (M <= 0 || N <= 0 || K <= 0) return 0;
     size_t need = 0;  // the largest need over both transposes of either operand and the compute types
-    if (M <= 64 && K % 128 == 0 && K >= 128) need = gemm_skinny_workspace_bytes(M, N, K);  // few-row products (gemm_skinny.hip)
+    if (M <= 64 && K % 128 == 0 && K >= 128 && (long)cdiv(N, 32) * cdiv(M, 32) <= GEMM_SPLITK_MAX_TILES)
+        need = gemm_skinny_workspace_bytes(M, N, K);  // few-row products (gemm_skinny.hip)
     for (int ta = 0; ta < 2; ++ta)
         for (int tb = 0; tb < 2; ++tb)
             for (int dtype : {CAPDEC_F32, CAPDEC_BF16, CAPDEC_F32X3, CAPDEC_BF16S}) {
@@ -454,6 +457,7 @@ extern "C" int capdec_gemm(int transA, int transB, int M, int N, int K, const vo
         p.drop = make_dropout(ep->drop_p, ep->drop_seed);
         p.c16 = (__bf16*)ep->c16;
         p.ldc16 = ep->ldc16;
+        p.unpadded = ep->bf16_unpadded;
         CAPDEC_REQUIRE(!p.c16 || (ep->ldc16 >= N && !ep->ce_partials), "capdec_gemm: c16 needs ldc16 >= N (and no ce_partials)");
         p.ce_part = (float4*)ep->ce_partials;
         p.ce_lse = (const float*)ep->ce_lse;

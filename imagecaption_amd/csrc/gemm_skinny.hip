@@ -1,12 +1,12 @@
 // Skinny fp32 product for decode steps: C[M, N] = epilogue(A[M, K] * B[N, K]^T) with M of a few dozen rows (one
 // token per caption: the reference's sampler at its own batch sizes, ref train.py:289-412; greedy / beam steps).
 // The tiled kernel of gemm_f32.hip needs 64-row tiles and in-launch split-K to find any parallelism in such a
-// shape (8 column tiles x K slices, tickets, slab round trips: 13.6 us for 32 x 512 x 512); here one 512-thread
-// workgroup owns a 32 x 32 output block and its EIGHT WAVES SPLIT K among themselves (combined through LDS in wave
-// order: deterministic), so a 512-wide layer is 16 independent workgroups with no global hand-off at all.
+// shape (8 column tiles x K slices, tickets, slab round trips: 13.6 us for 32 x 512 x 512); here one 1024-thread
+// workgroup owns a 32 x 32 output block and its SIXTEEN WAVES SPLIT K among themselves (combined through 67.6 KB of
+// LDS in wave order: deterministic), so a 512-wide layer is 16 independent workgroups with no global hand-off at all.
 //
 // Exact fp32 (v_mfma_f32_32x32x2_f32).  The MFMA sums over k in whatever order the lanes present it, so lane
-// (l31, half) of wave w walks the CONTIGUOUS k-run  w * K/8 + half * K/16 .. + K/16  of its row -- 16-byte loads
+// (l31, half) of wave w walks the CONTIGUOUS k-run  w * K/16 + half * K/32 .. + K/32  of its row -- 16-byte loads
 // straight from global memory in operand layout, no LDS staging, no wasted elements.
 #include "common.h"
 #include "gemm_common.h"
@@ -77,7 +77,7 @@ __global__ __launch_bounds__(SK_NT) void gemm_skinny_f32_kernel(GemmParams p) {
 #pragma unroll
     for (int r = 0; r < 16; ++r) red[wave][(r & 3) + 8 * (r >> 2) + 4 * half][l31] = acc[r];
     __syncthreads();
-    // 1024 outputs, 512 threads: thread -> column tid & 31, rows (tid >> 5) and (tid >> 5) + 16
+    // 1024 outputs, SK_NT threads: thread -> column tid & 31, row(s) (tid >> 5) + (SK_NT / 32) * e
     const int n = en;
     float vsum[SK_EPT];
 #pragma unroll
@@ -133,11 +133,16 @@ __global__ __launch_bounds__(SK_NT) void gemm_skinny_f32_kernel(GemmParams p) {
     }
 }
 
-// x[M, K] * W[N, K]^T with few rows: exact fp32, K a multiple of 64 (8 waves x 2 lane halves x one float4),
-// 16-byte aligned operands with leading dimensions that are multiples of 4; no bias-gradient sums / CE partials
+int gemm_skinny_slices(int K);
+
+// x[M, K] * W[N, K]^T with few rows: exact fp32, K a multiple of 128 (16 waves x 2 lane halves x one float4),
+// 16-byte aligned operands with leading dimensions that are multiples of 4; no bias-gradient sums / CE partials;
+// a K-sliced launch takes one ticket per 32 x 32 block, so more blocks than tickets go to the tiled kernel instead
 bool gemm_skinny_ok(const GemmParams& p, bool AK, bool BKM, int dtype) {
-    return dtype == CAPDEC_F32 && AK && BKM && p.M <= 64 && p.K % (8 * SK_WAVES) == 0 && p.K >= 128 && p.lda % 4 == 0 && p.ldb % 4 == 0 &&
-           aligned16(p.A) && aligned16(p.B) && !p.colsum && !p.ce_part && !p.ce_lse && !p.c16;
+    if (!(dtype == CAPDEC_F32 && AK && BKM && p.M <= 64 && p.K % (8 * SK_WAVES) == 0 && p.K >= 128 && p.lda % 4 == 0 &&
+          p.ldb % 4 == 0 && aligned16(p.A) && aligned16(p.B) && !p.colsum && !p.ce_part && !p.ce_lse && !p.c16))
+        return false;
+    return gemm_skinny_slices(p.K) <= 1 || (long)cdiv(p.N, 32) * cdiv(p.M, 32) <= GEMM_SPLITK_MAX_TILES;
 }
 
 // K slices per output block: a function of K ALONE (512 of K per workgroup, at most 8 slices), so that a product's
@@ -159,7 +164,7 @@ int launch_gemm_skinny(GemmParams p, void* workspace, size_t workspace_bytes, hi
     const int s = gemm_skinny_slices(p.K);
     if (s > 1) {
         const size_t need = gemm_skinny_workspace_bytes(p.M, p.N, p.K);
-        if (!workspace || workspace_bytes < need || !aligned16(workspace) || cdiv(p.N, 32) * cdiv(p.M, 32) > GEMM_SPLITK_MAX_TILES) {
+        if (!workspace || workspace_bytes < need || !aligned16(workspace)) {
             set_error("capdec_gemm: the few-row product needs %zu workspace bytes (16-byte aligned) for its K slices, got %zu",
                       need, workspace_bytes);
             return CAPDEC_ERR_WORKSPACE;

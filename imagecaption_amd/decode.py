@@ -67,7 +67,8 @@ class CaptionDecoder:
         l = lib()
         x = ops.embed_fwd(tok.view(R, 1), m.embedding.weight, st["pe"], t0=t).view(R, d)
         anc = ptr(st["anc"][st["cur"]])
-        if self.fused_step:
+        # the one-call step takes fp32 matrices only: bf16 storage keeps the op-by-op path, whose products cast operands
+        if self.fused_step and ops.COMPUTE_DTYPE != ops.BF16S:
             dff = st["dff"]
             need = st["gemm_need"].get(R)
             if need is None:

@@ -247,7 +247,7 @@ def stack_bwd(layers, grads, norm_w, norm_b, g_norm_w, g_norm_b, sv, dy, mem, B,
             pitch = ops._bf16_pitch(w_all.shape[0])
             buf = torch.empty((mem.shape[0], pitch), dtype=torch.bfloat16, device=dy.device)
             buf[:, w_all.shape[0]:].zero_()
-            dkv_all = buf[:, :w_all.shape[0]]
+            dkv_all = ops._zero_padded(buf[:, :w_all.shape[0]])
         else:
             dkv_all = torch.empty((mem.shape[0], w_all.shape[0]), dtype=torch.float32, device=dy.device)
     for l in range(len(layers) - 1, -1, -1):

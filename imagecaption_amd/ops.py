@@ -51,7 +51,27 @@ def cast_bf16(t):
     ldd = _bf16_pitch(Cc)
     dst = torch.empty((R, ldd), dtype=torch.bfloat16, device=t.device)
     check(lib().capdec_cast_bf16(ptr(t), t.stride(0), ptr(dst), ldd, R, Cc, stream()), "capdec_cast_bf16")
-    return dst[:, :Cc]
+    return _zero_padded(dst[:, :Cc])
+
+
+def _zero_padded(view):
+    """Mark a bf16 [R, C] view whose buffer holds ZEROS in the columns C .. pitch-1 behind every row (the cast kernels
+    write them).  Only such operands may run a reduction over C % 64 != 0 on the LDS-DMA products, which cannot mask a
+    load; any other bf16 view (a column slice of a wider matrix, an uninitialised tail: the mark does not survive
+    slicing) is flagged to capdec_gemm (capdec_epilogue.bf16_unpadded) and takes the register-staged kernel."""
+    view._capdec_zero_padded = True
+    return view
+
+
+def _unpadded_bits(a, b, trans_a, trans_b, K):
+    if K % 64 == 0:
+        return 0
+    bits = 0
+    if not trans_a and not getattr(a, "_capdec_zero_padded", False):
+        bits |= 1
+    if trans_b and not getattr(b, "_capdec_zero_padded", False):
+        bits |= 2
+    return bits
 
 
 def _bf16_operand(t, name):
@@ -84,8 +104,9 @@ class Bf16Copies:
         for t in self.sources:
             _mat(t, "Bf16Copies.src")
         if copies is None:
-            copies = [torch.empty((t.shape[0], _bf16_pitch(t.shape[1])), dtype=torch.bfloat16, device=t.device)[:, :t.shape[1]]
-                      for t in self.sources]
+            # (capdec_cast_bf16_multi writes the zero padding behind every row, like capdec_cast_bf16)
+            copies = [_zero_padded(torch.empty((t.shape[0], _bf16_pitch(t.shape[1])), dtype=torch.bfloat16,
+                                               device=t.device)[:, :t.shape[1]]) for t in self.sources]
         self.copies = list(copies)
         descs = (_capi.CastDesc * len(self.sources))()
         for d, t, c in zip(descs, self.sources, self.copies):
@@ -409,6 +430,8 @@ def gemm(a, b, trans_a, trans_b, out=None, bias=None, addend=None, pre=None, aux
     if colsum is not None and colsum.numel() != M:
         raise _capi.CapdecError("gemm: colsum must have M elements")
     ep.act, ep.drop_p, ep.drop_seed = act, float(drop_p), int(seed) & 0xFFFFFFFFFFFFFFFF
+    if COMPUTE_DTYPE == _capi.BF16S:
+        ep.bf16_unpadded = _unpadded_bits(a, b, trans_a, trans_b, K)
     if out16:
         if ce_partials is not None:
             raise _capi.CapdecError("gemm: a bf16 result cannot be combined with ce_partials")
@@ -480,7 +503,7 @@ def layernorm_fwd(x, gamma, beta, eps=1e-5, act=ACT_NONE, drop_p=0.0, seed=0, sa
         check(lib().capdec_layernorm_fwd_y16(ptr(x), ptr(gamma), ptr(beta), ptr(y), ptr(y16), y16.stride(0), ptr(mean),
                                              ptr(rstd), M, d, float(eps), act, float(drop_p), int(seed), stream()),
               "capdec_layernorm_fwd_y16")
-        BF16_MEMO[(y.data_ptr(), M, d, y.stride(0))] = (y, y16[:, :d])
+        BF16_MEMO[(y.data_ptr(), M, d, y.stride(0))] = (y, _zero_padded(y16[:, :d]))  # the kernel zeroes the padding
         return y, mean, rstd
     check(lib().capdec_layernorm_fwd(ptr(x), ptr(gamma), ptr(beta), ptr(y), ptr(mean), ptr(rstd), M, d, float(eps), act,
                                      float(drop_p), int(seed), stream()), "capdec_layernorm_fwd")
@@ -515,7 +538,7 @@ def layernorm_bwd(dy, x, gamma, beta, mean, rstd, act=ACT_NONE, drop_p=0.0, seed
             SIDE.run(fin, part, dgamma, dbeta)
         else:
             fin()
-        return dx, dd16[:, :d], dgamma, dbeta
+        return dx, _zero_padded(dd16[:, :d]), dgamma, dbeta
     if SIDE is not None:
         # the parameter gradients are weight gradients: their reduction runs on the weight-gradient lane, from a
         # private block of partials (the shared workspace would be overwritten by the next call on this stream)
@@ -807,7 +830,7 @@ def ce_dlogits_bf16(logits, lse, targets, eps, grad_scale):
     dst = torch.empty((rows, ldd), dtype=torch.bfloat16, device=logits.device)
     check(lib().capdec_ce_dlogits_bf16(ptr(logits), logits.stride(0), ptr(lse), ptr(targets), rows, V, float(eps),
                                         float(grad_scale), ptr(dst), ldd, stream()), "capdec_ce_dlogits_bf16")
-    return dst[:, :V]
+    return _zero_padded(dst[:, :V])
 
 
 def reduce_sum(x, scale=1.0):

@@ -111,6 +111,55 @@ class BucketReducer:
             torch.cuda.current_stream().wait_stream(self.side)
 
 
+class EqualRowsGuard:
+    """Data-parallel steps pre-scale the loss gradient by 1/(rows * world), which is exact only if every rank runs the
+    same B*T.  ``step(rows)`` is called by EVERY rank on EVERY step and always issues the same tiny collective
+    (MAX over [rows, -rows]), so the ranks' collective sequences can never diverge -- a check that only some ranks
+    enter (say, only those whose shape changed) would pair its all-reduce with the other ranks' next gradient bucket.
+
+    The verdict is read without stalling the pipeline: a rank whose own shape changed (and every rank on the first
+    step) reads it at once; otherwise the two words travel to pinned host memory behind the collective and are
+    looked at when the next step starts (``verify``), one step late but before any further work is enqueued.
+    gloo groups (CPU tests, one-GPU rehearsals) exchange host tensors and check immediately."""
+
+    def __init__(self, process_group=None, device=None):
+        self.pg = process_group
+        self.world = dist.get_world_size(process_group) if (dist.is_available() and dist.is_initialized()) else 1
+        dev = torch.device("cpu") if device is None else torch.device(device)
+        if self.world > 1 and dist.get_backend(process_group) == "gloo":
+            dev = torch.device("cpu")
+        self.device, self.rows, self.pending = dev, None, None
+
+    @staticmethod
+    def _judge(lo_hi):
+        hi, lo = int(lo_hi[0]), -int(lo_hi[1])
+        if hi != lo:
+            raise RuntimeError(f"CaptionTrainer: ranks run different batch shapes (B*T between {lo} and {hi}); "
+                               f"data-parallel steps need equal per-rank batches")
+
+    def verify(self):
+        if self.pending is not None:
+            (host, ev), self.pending = self.pending, None
+            ev.synchronize()
+            self._judge(host)
+
+    def step(self, rows):
+        if self.world == 1:
+            return
+        self.verify()
+        t = torch.tensor([rows, -rows], dtype=torch.int64).to(self.device)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX, group=self.pg)
+        changed, self.rows = self.rows != rows, rows
+        if self.device.type == "cpu" or changed:
+            self._judge(t)
+            return
+        host = torch.empty(2, dtype=torch.int64, pin_memory=True)
+        host.copy_(t, non_blocking=True)
+        ev = torch.cuda.Event()
+        ev.record()
+        self.pending = (host, ev)
+
+
 def shard_indices(n, rank, world, epoch=0, seed=42, shuffle=True):
     """Seeded per-rank partition of range(n) replacing DataLoader(shuffle=True) (ref main.py:63-70).
 

@@ -24,7 +24,7 @@ import torch.distributed as dist
 
 from . import engine, ops
 from .engine import DropoutPlan
-from .parallel import BucketReducer, FlatParams, decoder_param_groups
+from .parallel import BucketReducer, EqualRowsGuard, FlatParams, decoder_param_groups
 
 
 class FusedAdamW(torch.optim.Optimizer):
@@ -97,7 +97,9 @@ class CaptionTrainer:
         # off (then each weight is cast by the first product of the step that reads it: same values, ~40 launches)
         self._w16, self.one_launch_weight_casts = None, True
         self.side = ops.SideStream(dev) if (side_stream_wgrad and dev.type == "cuda") else None
-        self._rows = None  # B*T of the first step; data-parallel ranks must all run this many rows (1/(rows*world))
+        # data-parallel ranks must all run the same B*T (the loss gradient is pre-scaled by 1/(rows*world)): checked by
+        # a collective that every rank issues on every step (parallel.EqualRowsGuard)
+        self._rows_guard = EqualRowsGuard(process_group, dev)
         if self.world > 1:
             # every rank must start from the same parameters (the ranks only ever exchange gradients): rank 0's win
             dist.broadcast(self.flat_p, src=dist.get_global_rank(process_group, 0) if process_group is not None else 0,
@@ -117,16 +119,6 @@ class CaptionTrainer:
     betas = property(lambda self: self._group_get("betas"), lambda self, v: self._group_set("betas", tuple(v)))
     eps = property(lambda self: self._group_get("eps"), lambda self, v: self._group_set("eps", v))
     wd = property(lambda self: self._group_get("weight_decay"), lambda self, v: self._group_set("weight_decay", v))
-
-    def _check_equal_rows(self, rows):
-        """The loss gradient is pre-scaled by 1/(rows * world): exact only if every rank runs the same B*T."""
-        if self.world > 1 and self._rows != rows:
-            t = torch.tensor([rows, -rows], dtype=torch.int64, device=self.flat_p.device)
-            dist.all_reduce(t, op=dist.ReduceOp.MAX, group=self.pg)
-            if int(t[0]) != -int(t[1]):
-                raise RuntimeError(f"CaptionTrainer: ranks run different batch shapes (B*T between {-int(t[1])} and "
-                                   f"{int(t[0])}); data-parallel steps need equal per-rank batches")
-        self._rows = rows
 
     def _refresh_views(self):
         m = self.model
@@ -172,7 +164,7 @@ class CaptionTrainer:
         tgt_in = captions[:, :-1].contiguous()   # ref train.py:29
         tgt_out = captions[:, 1:].contiguous()   # ref train.py:30
         B, T = tgt_in.shape
-        self._check_equal_rows(B * T)
+        self._rows_guard.step(B * T)
         # each rank draws its own dropout masks (rank folded into the key): the same masks on different data would
         # correlate the noise across the global batch
         dp = DropoutPlan(self.p if train else 0.0, self.seed ^ engine._splitmix64(self.rank) if self.rank else self.seed,
@@ -289,6 +281,7 @@ class CaptionTrainer:
         """Raise IndexError if a step since the last call saw token ids outside the vocabulary (synchronises: call it
         once per epoch or per logging interval, not per step)."""
         ops.check_ids()
+        self._rows_guard.verify()
 
     def optimizer_step(self):
         self.step_count += 1

@@ -87,6 +87,13 @@ typedef struct capdec_epilogue {
      * only readers take bf16 (the cross-attention K | V block of the bf16 storage path: capdec_attn_fwd_kv16). */
     void* c16;
     int ldc16;
+    /* CAPDEC_BF16S operands whose reduction index is the contiguous one (A with transA = 0, B with transB = 1): a row
+     * pitch that covers K rounded up to 64 is taken to mean that the elements K .. pitch-1 behind every row are ZERO
+     * (capdec_cast_bf16 / capdec_ce_dlogits_bf16 write those zeros), and the LDS-DMA kernels -- which cannot mask a
+     * load -- then run the reduction tail through them.  A caller whose pitch is that wide for another reason (a
+     * column slice of a wider matrix, an uninitialised tail) sets bit 0 (A) / bit 1 (B): the product then takes the
+     * register-staged kernel, which masks.  Irrelevant when K is a multiple of 64. */
+    int bf16_unpadded;
 } capdec_epilogue;
 
 /* Split-K (chosen by the built-in cost model for small outputs with a long K, e.g. weight gradients) is combined
@@ -383,6 +390,8 @@ int capdec_decode_attn(const void* q, int ldq, const void* k, const void* v, int
  * results; what it removes is the caller's per-launch host cost, which bounds small-batch decode (the reference's
  * sampler, ref train.py:289-412, at its own batch sizes).  Tmax / W are the cache geometry of capdec_decode_attn;
  * every pointer of a layer is a device pointer, all matrices dense (row stride = their width), fp32.
+ * dtype: CAPDEC_F32 / CAPDEC_BF16 / CAPDEC_F32X3 (arithmetic of the products on those fp32 matrices); CAPDEC_BF16S is
+ * refused with CAPDEC_ERR_ARG (its products read bf16 copies, which this call does not hold).
  * workspace: capdec_decode_step_workspace_bytes(R, d, dff) bytes, 16-byte aligned; gemm_workspace: a capdec_gemm
  * workspace (ticket words zeroed once), capdec_gemm_workspace_bytes of the largest product. */
 typedef struct capdec_decode_layer {

@@ -107,6 +107,40 @@ def test_gemm_reads_bf16_operands_in_either_orientation(M, N, K, ta, tb):
         assert relerr(o, ref) < 2e-6 * math.sqrt(K), i
 
 
+@pytest.mark.parametrize("ta,tb", [(0, 1), (0, 0), (1, 1)])
+def test_column_slice_of_a_wider_bf16_matrix_is_not_mistaken_for_zero_padding(ta, tb):
+    """A bf16 operand that is a column slice of a wider matrix has a pitch that covers K rounded up to 64 -- but what
+    lies behind column K is the neighbour's data (here: NaN), not the cast kernel's zero padding.  The LDS-DMA
+    kernels cannot mask a load; such views are flagged (capdec_epilogue.bf16_unpadded) and take the masking kernel."""
+    ops = _ops()
+    M, N, K = 130, 140, 100   # K % 64 != 0
+    g = torch.Generator().manual_seed(11 + ta * 2 + tb)
+    a = torch.randn((K, M) if ta else (M, K), generator=g)
+    b = torch.randn((N, K) if tb else (K, N), generator=g)
+    ref = (r16(a).T if ta else r16(a)) @ (r16(b).T if tb else r16(b))
+
+    def wide(t):  # t as the leading columns of a 256-wide bf16 matrix whose other columns are NaN
+        w = torch.full((t.shape[0], 256), float("nan"), dtype=torch.bfloat16, device=DEV)
+        w[:, :t.shape[1]] = t.to(DEV).to(torch.bfloat16)
+        return w[:, :t.shape[1]]
+
+    from imagecaption_amd import _capi
+    l = _capi.lib()
+    with ops.compute_dtype("bf16s"):
+        outs = [ops.gemm(wide(a), wide(b), ta, tb)]
+        try:
+            for bm, bn, bk in ((128, 128, 0), (128, 128, 32), (256, 256, 0), (64, 64, 0)):  # forced DMA plans fall back too
+                l.capdec_gemm_tune(bm, bn, 1, bk)
+                outs.append(ops.gemm(wide(a), wide(b), ta, tb))
+        finally:
+            l.capdec_gemm_tune(0, 0, 0, 0)
+        # ... while the casts' own copies keep the DMA kernels and give the same numbers
+        outs.append(ops.gemm(ops.cast_bf16(a.to(DEV)), ops.cast_bf16(b.to(DEV)), ta, tb))
+    for i, o in enumerate(outs):
+        assert torch.isfinite(o).all(), i
+        assert relerr(o, ref) < 2e-6 * math.sqrt(K), i
+
+
 def test_gemm_asymmetric_identity_all_layouts():
     """A = I with an asymmetric B catches swapped row / column maps and a wrong register transpose (values are small
     integers: exact in bf16)."""

@@ -349,6 +349,38 @@ def test_one_call_decode_step_is_bit_identical_to_the_op_by_op_path(S):
     assert torch.equal(one.sample(feats, max_len=40, seed=5), ops_.sample(feats, max_len=40, seed=5))
 
 
+@pytest.mark.parametrize("S", [1, 5])
+def test_bf16_storage_decode_takes_the_op_by_op_path_and_the_one_call_step_refuses_that_type(S):
+    """capdec_decode_step's matrices are fp32: handed CAPDEC_BF16S it would read them as bf16 (silently wrong captions).
+    The C call refuses the type, and CaptionDecoder(dtype="bf16s", fused_step=True) therefore runs the op-by-op path,
+    whose products cast their operands: identical tokens to fused_step=False, and greedy ids equal to the fp32
+    decoder's wherever the golden's top-1 / top-2 margin is far above bf16 noise."""
+    import ctypes as C
+    from imagecaption_amd import _capi
+    from imagecaption_amd._capi import lib, ptr, stream
+    from imagecaption_amd.decode import CaptionDecoder
+    model = _tiny_model()
+    gold = np.load(os.path.join(GOLDEN, f"tiny_S{S}.npz"))
+    feats = torch.from_numpy(gold["features"]).to(DEV)
+    one, ops_ = CaptionDecoder(model, dtype="bf16s", fused_step=True), CaptionDecoder(model, dtype="bf16s", fused_step=False)
+    ga, gb = one.greedy(feats, max_len=12), ops_.greedy(feats, max_len=12)
+    assert torch.equal(ga, gb)
+    (ia, sa), (ib, sb) = one.beam(feats, beam=3, max_len=12), ops_.beam(feats, beam=3, max_len=12)
+    assert torch.equal(ia, ib) and torch.equal(sa, sb)
+    assert torch.isfinite(sa).all()
+    # against the fp32 decoder: the first tokens (before a bf16-level near-tie can fork a caption) agree
+    g32 = CaptionDecoder(model).greedy(feats, max_len=12)
+    assert float((ga[:, :2] == g32[:, :2]).float().mean()) > 0.8
+    # the raw C call refuses the type
+    st = one._prepare(feats, 1, 12)
+    x = torch.zeros(st["R"], one.d, device=DEV)
+    ws = torch.empty(lib().capdec_decode_step_workspace_bytes(st["R"], one.d, st["dff"]), dtype=torch.uint8, device=DEV)
+    gws = torch.zeros(1 << 20, dtype=torch.uint8, device=DEV)
+    rc = lib().capdec_decode_step(C.cast(st["layers_c"], C.c_void_p), one.L, ptr(x), ptr(st["anc"][0]), st["R"], one.H, one.d,
+                                  st["dff"], 12, 0, 1, st["S"], _capi.BF16S, ptr(ws), ws.numel(), ptr(gws), gws.numel(), stream())
+    assert rc == -1 and b"BF16S" in lib().capdec_last_error()
+
+
 @pytest.mark.parametrize("H,dh,t", [(2, 64, 50), (8, 64, 199), (2, 32, 17), (1, 128, 64)])
 def test_split_key_self_attention_for_small_batches_matches_the_one_wave_kernel(H, dh, t):
     """capdec_decode_attn picks a four-waves-per-(row, head) kernel for small batches with a long prefix; the same

@@ -7,7 +7,7 @@ import torch.distributed as dist
 import torch.multiprocessing as mp
 
 from imagecaption_amd.engine import DropoutPlan
-from imagecaption_amd.parallel import BucketReducer, FlatParams, shard_indices, shard_range
+from imagecaption_amd.parallel import BucketReducer, EqualRowsGuard, FlatParams, shard_indices, shard_range
 from oracle.torch_oracle import OracleCaptionDecoder, label_smoothed_loss, synthetic_captions
 
 TINY = dict(vocab_size=50, d_model=64, nhead=2, num_decoder_layers=2, feature_dim=24)
@@ -87,6 +87,37 @@ def test_bucketed_allreduce_equals_global_batch_gradient_gloo_world2():
             err, norms = out[rank]
             assert err < 1e-5, err
             assert norms[0] == norms[1]  # every rank clips by the same global norm
+
+
+def _rows_worker(rank, world, port, out):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    guard = EqualRowsGuard()
+    bucket = torch.full((4,), float(rank + 1))
+    log = []
+    # steps 0, 1: equal shapes.  Step 2: ONLY rank 1 gets a short last batch, rank 0 repeats its shape -- the case a
+    # check that only "changed" ranks enter turns into a mismatched collective (hang or corrupted gradients).
+    for step, rows in enumerate([(240, 240), (240, 240), (240, 96)]):
+        try:
+            guard.step(rows[rank])
+            log.append("ok")
+        except RuntimeError as e:
+            log.append("raised" if "96 and 240" in str(e) else f"wrong message: {e}")
+        # the gradient collective that follows must still pair up across ranks, on every step
+        g = bucket.clone()
+        dist.all_reduce(g, op=dist.ReduceOp.SUM)
+        log.append(float(g[0]))
+    out[rank] = log
+    dist.destroy_process_group()
+
+
+def test_equal_rows_guard_fires_on_every_rank_when_only_one_rank_changes_shape_gloo_world2():
+    world, port = 2, _free_port()
+    with mp.Manager() as mgr:
+        out = mgr.dict()
+        mp.spawn(_rows_worker, args=(world, port, out), nprocs=world, join=True)
+        for rank in range(world):
+            assert out[rank] == ["ok", 3.0, "ok", 3.0, "raised", 3.0], (rank, out[rank])
 
 
 def test_sharding_helpers():

@@ -153,6 +153,7 @@ class compute_dtype:
 # (High-priority streams would separate the queues by construction, but on this ROCm stack they deadlock -- the
 # 4th one created in a process, or any of them after a hipGraph launch: tools/hp_stream_probe.py.)
 _LANES = {}
+LANE_INFO = {}  # the same key -> (candidates tried, whether the kept one was measured to run beside the others)
 
 
 def _runs_beside(base, cand, device):
@@ -192,13 +193,15 @@ def lane_stream(device, slot=0):
     key = (index, cur.cuda_stream, slot)
     if key not in _LANES:
         others = [lane_stream(device, s) for s in range(slot)]
-        cand = None
+        cand, accepted = None, False
         for attempt in range(8):
             cand = torch.cuda.Stream(device=device)
             if _runs_beside_current(cand, device) and all(_runs_beside(o, cand, device) for o in others):
+                accepted = True
                 break
+        LANE_INFO[key] = (attempt + 1, accepted)
         if os.environ.get("CAPDEC_DEBUG_LANE"):
-            print(f"[capdec] lane stream (slot {slot}): candidate #{attempt} {'runs beside' if attempt < 7 else 'last tried for'} "
+            print(f"[capdec] lane stream (slot {slot}): candidate #{attempt} {'runs beside' if accepted else 'last tried for'} "
                   f"stream {cur.cuda_stream:#x}", file=sys.stderr, flush=True)
         _LANES[key] = cand  # the last candidate if none qualified: correct, merely without overlap
     return _LANES[key]

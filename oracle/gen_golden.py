@@ -14,6 +14,8 @@ Outputs (all small, data only):
 * c1_shape.npz                C1 shape (d=512, V=108, T=299, B=2): logits, loss, grad norm
 * c2_shape.npz                bench workload (C2, B=256): 64 sampled logit rows, loss, global and
                               per-parameter gradient norms (weights are rebuilt from seed 42)
+* c3_shape.npz                configs[2] at full size (C3, B=256, d 1024, V 30 000, S 196): the same summary
+                              (`python -m oracle.gen_golden c3`; not in the default set: minutes of CPU time)
 * decode_tiny.npz             greedy / beam-3 / beam-5 ids + scores + logit-gap margins (tiny config)
 """
 import json
@@ -163,6 +165,34 @@ def gen_c2_shape():
     print(f"c2 shape: loss {loss.item():.6f} grad-norm {gn:.6f}")
 
 
+def c3_batch(B=256, S=196, din=512, T=20, V=30000, seed=1234):
+    """BASELINE.json configs[2] (C3): 14 x 14 x 512 grid features, hidden 1024, vocabulary 30 000."""
+    gen = torch.Generator().manual_seed(seed)
+    features = torch.randn(B, S, din, generator=gen)
+    return features, synthetic_captions(B, T, V, gen)
+
+
+def gen_c3_shape():
+    """configs[2] at FULL size (B = 256, d 1024, dh 128, V 30 000, S 196), summarised like c2_shape.npz: 64 sampled
+    logit rows, loss, global and per-parameter gradient norms, weight checksum (weights rebuilt from seed 42)."""
+    torch.manual_seed(42)
+    model = OracleCaptionDecoder(vocab_size=30000, d_model=1024, nhead=8, num_decoder_layers=6, feature_dim=512)
+    model.eval()
+    features, ids = c3_batch()
+    logits = model(features, ids[:, :-1])
+    loss = label_smoothed_loss(logits, ids[:, 1:])
+    loss.backward()
+    names = [n for n, _ in model.named_parameters()]
+    norms = np.array([float(p.grad.double().pow(2).sum().sqrt()) for _, p in model.named_parameters()])
+    gn = float(np.sqrt((norms ** 2).sum()))
+    rows = torch.randperm(logits.shape[0] * logits.shape[1], generator=torch.Generator().manual_seed(7))[:64]
+    flat = logits.detach().reshape(-1, logits.shape[-1])
+    np.savez_compressed(f"{OUT}/c3_shape.npz", rows=rows.numpy(), logit_rows=flat[rows].numpy(),
+                        loss=loss.detach().numpy(), grad_norm=np.float64(gn), param_names=np.array(names),
+                        param_grad_norms=norms, weight_checksum=np.float64(sum(float(p.detach().double().sum()) for p in model.parameters())))
+    print(f"c3 shape: loss {loss.item():.6f} grad-norm {gn:.6f}")
+
+
 def gen_decode():
     out = {}
     for S in (1, 5):
@@ -201,6 +231,8 @@ def main():
         gen_c1_shape()
     if "c2" in which:
         gen_c2_shape()
+    if "c3" in which:  # minutes of CPU time and ~20 GB of host memory: not part of the default set
+        gen_c3_shape()
     if "decode" in which:
         gen_decode()
 

@@ -59,6 +59,7 @@ SIGNATURES = {
     "capdec_embed_bwd": (_i, [_vp, _vp, _vp, _i, _i, _i, _i, _f, _u64, _vp, _sz, _vp]),
     "capdec_embed_bwd_plan": (_i, [_vp, _i, _i, _i, _i, _vp, _sz, _vp]),
     "capdec_embed_bwd_apply": (_i, [_vp, _vp, _vp, _i, _i, _i, _i, _f, _u64, _vp, _sz, _vp]),
+    "capdec_attn_tune": (_i, [_i]),
     "capdec_attn_fwd": (_i, [_vp, _i, _vp, _i, _vp, _i, _vp, _i, _vp, _i, _i, _i, _i, _i, _i, _f, _f, _u64, _vp]),
     "capdec_attn_bwd": (_i, [_vp, _i, _vp, _i, _vp, _i, _vp, _i, _vp, _i, _vp, _vp, _vp, _i, _vp, _i, _vp, _i,
                              _i, _i, _i, _i, _i, _i, _f, _f, _u64, _vp]),

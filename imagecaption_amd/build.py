@@ -20,6 +20,7 @@ FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-fno-gpu-rdc", 
 # rescale, masking, bf16 packing, stores) otherwise pay a v_accvgpr_read / _write pair around every such touch.
 FILE_FLAGS = {
     "attention_bf16.hip": ["-mllvm", "-amdgpu-mfma-vgpr-form=1"],
+    "attention_f32_ring.hip": ["-mllvm", "-amdgpu-mfma-vgpr-form=1"],
 }
 
 

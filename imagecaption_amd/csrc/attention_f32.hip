@@ -20,17 +20,6 @@
 
 namespace capdec {
 
-struct AttnParams {
-    const float* q; const float* k; const float* v; const float* o; const float* dout;
-    float* out; float* lse; float* delta; float* dq; float* dk; float* dv;
-    int ldq, ldk, ldv, ldo, lddo, lddq, lddk, lddv;
-    int B, H, Tq, Tk, causal;
-    int dkv_bf16;  // dk / dv point to bf16 matrices (lddk / lddv in bf16 elements): capdec_attn_bwd_dkv16
-    int kv_bf16;   // k / v point to bf16 matrices (ldk / ldv in bf16 elements): capdec_attn_*_kv16
-    float scale;
-    Dropout drop;
-};
-
 // A 32 x DH tile moves global -> registers (coalesced: 16 consecutive lanes read one 256-B row
 // piece) -> LDS, in two separate steps so the global loads of the NEXT tile can be in flight
 // while the current one is being multiplied (register prefetch, no extra LDS).
@@ -595,6 +584,15 @@ static bool ok_mat(const void* p, int ld, int H, int dh) { return p && aligned16
 
 using namespace capdec;
 
+// 0 = the ring kernels (attention_f32_ring.hip) wherever they cover the call, 1 = the legacy one-item-per-wave kernels
+// everywhere (tests compare the two bit for bit; measurements)
+static int g_attn_mode = 0;
+extern "C" int capdec_attn_tune(int mode) {
+    CAPDEC_REQUIRE(mode == 0 || mode == 1, "capdec_attn_tune: mode %d not in {0 = auto, 1 = legacy kernels}", mode);
+    g_attn_mode = mode;
+    return CAPDEC_OK;
+}
+
 static int attn_fwd_impl(const void* q, int ldq, const void* k, int ldk, const void* v, int ldv, void* o, int ldo,
                          void* lse, int B, int H, int Tq, int Tk, int dh, int causal, float scale, float drop_p,
                          uint64_t drop_seed, capdec_stream_t stream, int kv_bf16) {
@@ -616,6 +614,7 @@ static int attn_fwd_impl(const void* q, int ldq, const void* k, int ldk, const v
         hipLaunchKernelGGL(attn_s1_fwd_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, st, p, dh);
         return check_launch("capdec_attn_fwd");
     }
+    if (g_attn_mode == 0 && attn_ring_fwd(p, dh, st)) return check_launch("capdec_attn_fwd");
     if (dh == 32) hipLaunchKernelGGL(attn_fwd_kernel<32>, grid, dim3(64), 0, st, p);
     else if (dh == 64) hipLaunchKernelGGL(attn_fwd_kernel<64>, grid, dim3(64), 0, st, p);
     else hipLaunchKernelGGL(attn_fwd_kernel<128>, grid, dim3(64), 0, st, p);
@@ -662,6 +661,7 @@ static int attn_bwd_impl(const void* q, int ldq, const void* k, int ldk, const v
         hipLaunchKernelGGL(attn_s1_bwd_kernel, dim3(B * (H * dh / 64)), dim3(256), 0, st, p, dh);
         return check_launch("capdec_attn_bwd");
     }
+    if (g_attn_mode == 0 && attn_ring_bwd(p, dh, st)) return check_launch("capdec_attn_bwd");
     const dim3 gq(B * H * ((Tq + 31) / 32)), gk(B * H * ((Tk + 31) / 32));
     if (dh == 32) {
         hipLaunchKernelGGL(attn_bwd_dq_kernel<32>, gq, dim3(64), 0, st, p);

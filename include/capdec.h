@@ -260,6 +260,10 @@ int capdec_attn_bwd(const void* q, int ldq, const void* k, int ldk, const void* 
                     const void* dout, int lddo, const void* lse, void* delta, void* dq, int lddq, void* dk, int lddk,
                     void* dv, int lddv, int B, int H, int Tq, int Tk, int dh, int causal, float scale, float drop_p,
                     uint64_t drop_seed, capdec_stream_t stream);
+/* Kernel choice of capdec_attn_fwd / capdec_attn_bwd (process-global, not thread-safe; a tuning / test hook like
+ * capdec_gemm_tune): 0 = default (the persistent DMA-ring kernels wherever they cover the call: head dims 64 / 128,
+ * Tk > 1, fp32 K / V), 1 = the one-item-per-wave kernels everywhere.  Both forms give bit-identical results. */
+int capdec_attn_tune(int mode);
 /* Attention with K and V given as bf16 matrices (ldk / ldv in bf16 elements, multiples of 8; Tk > 1): they are
  * widened to fp32 on their way into LDS and everything else is capdec_attn_fwd / capdec_attn_bwd_dkv16 (dK / dV come
  * back as bf16 too).  For the bf16 storage path, whose K | V block exists only as bf16 (capdec_epilogue.c16): the

@@ -275,6 +275,37 @@ def test_attention_fwd_bwd(B, H, Tq, Tk, dh, causal):
         assert float((got.double().cpu() - ref).abs().max()) < 2e-5 * max(float(ref.abs().max()), 1.0)
 
 
+@pytest.mark.parametrize("B,H,Tq,Tk,dh,causal,p", [
+    (3, 8, 20, 49, 64, False, 0.1), (3, 8, 20, 20, 64, True, 0.1), (2, 2, 70, 33, 64, False, 0.0), (1, 4, 299, 299, 64, True, 0.1),
+    (2, 2, 1, 37, 64, True, 0.3), (2, 4, 20, 96, 64, True, 0.1), (9, 8, 5, 64, 64, False, 0.0), (2, 8, 32, 256, 64, False, 0.1),
+    (300, 8, 20, 49, 64, False, 0.1),   # more (b, h) items than resident workgroups: the persistent walk
+    (2, 3, 40, 40, 128, True, 0.1)])    # head dim 128: both settings run the legacy kernels
+def test_ring_attention_kernels_are_bit_identical_to_the_one_item_per_wave_kernels(B, H, Tq, Tk, dh, causal, p):
+    """capdec_attn_fwd / capdec_attn_bwd pick the persistent LDS-DMA ring kernels (attention_f32_ring.hip) where they
+    cover the call (head dim 64, Tk > 1; backward: one query tile); capdec_attn_tune(1) forces the one-item-per-wave
+    kernels.  Same products in the same order: outputs, lse, delta-free gradients equal to the bit -- with dropout on
+    (same regenerated masks), with row-strided views of packed projections, on ragged and multi-tile shapes."""
+    ops = _ops()
+    from imagecaption_amd._capi import lib, check
+    D = H * dh
+    g = torch.Generator().manual_seed(B * 131 + Tq * 7 + Tk + dh)
+    q = torch.randn(B * Tq, D, generator=g).to(DEV)
+    kv = torch.randn(B * Tk, 2 * D + 8, generator=g).to(DEV)  # K | V packed, with a ragged pitch
+    do = torch.randn(B * Tq, D, generator=g).to(DEV)
+    k, v = kv[:, :D], kv[:, D:2 * D]
+    res = {}
+    try:
+        for mode in (1, 0):
+            check(lib().capdec_attn_tune(mode))
+            o, lse = ops.attn_fwd(q, k, v, B, H, Tq, Tk, causal, p, 1234)
+            res[mode] = (o, lse) + tuple(ops.attn_bwd(q, k, v, o, do, lse, B, H, Tq, Tk, causal, p, 1234))
+    finally:
+        check(lib().capdec_attn_tune(0))
+    for a, b, name in zip(res[0], res[1], ("o", "lse", "dq", "dk", "dv")):
+        assert torch.isfinite(a).all(), name
+        assert torch.equal(a, b), name
+
+
 def test_attention_packed_qkv_slices():
     ops = _ops()
     B, H, T, dh = 2, 2, 20, 64

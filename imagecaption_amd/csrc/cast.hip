@@ -60,6 +60,40 @@ __global__ __launch_bounds__(256) void cast_bf16_multi_kernel(const capdec_cast_
     }
 }
 
+// the same table walk for plain fp32 copies (capdec_copy_f32_multi): groups of 4 floats, no padding written
+__global__ __launch_bounds__(256) void copy_f32_multi_kernel(const capdec_cast_desc* __restrict__ table, int n) {
+    int t = 0;
+    while (t + 1 < n && table[t + 1].first_block <= (int)blockIdx.x) ++t;
+    const capdec_cast_desc d = table[t];
+    const float* src = (const float*)d.src;
+    float* dst = (float*)d.dst;
+    const int c4 = (d.C + 3) / 4;
+    const size_t total = (size_t)d.R * c4;
+    for (size_t g = (size_t)((int)blockIdx.x - d.first_block) * 256 + threadIdx.x; g < total; g += (size_t)d.blocks * 256) {
+        const int r = (int)(g / c4), c0 = (int)(g % c4) * 4;
+        const float* s = src + (size_t)r * d.lds + c0;
+        float* o = dst + (size_t)r * d.ldd + c0;
+        if (d.vec && c0 + 4 <= d.C) {
+            *reinterpret_cast<float4*>(o) = *reinterpret_cast<const float4*>(s);
+        } else {
+            for (int e = 0; e < 4 && c0 + e < d.C; ++e) o[e] = s[e];
+        }
+    }
+}
+
+// captions [B, T1] (row stride ld) -> tgt_in = captions[:, :-1], tgt_out = captions[:, 1:], both dense [B, T1 - 1]
+__global__ __launch_bounds__(256) void shift_captions_kernel(const int64_t* __restrict__ cap, int ld, int B, int T1,
+                                                              int64_t* __restrict__ tin, int64_t* __restrict__ tout) {
+    const int T = T1 - 1;
+    const size_t total = (size_t)B * T;
+    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (size_t)gridDim.x * 256) {
+        const int b = (int)(i / T), t = (int)(i % T);
+        const int64_t a = cap[(size_t)b * ld + t], c = cap[(size_t)b * ld + t + 1];
+        tin[i] = a;
+        tout[i] = c;
+    }
+}
+
 // one workgroup per logits row: dst[m][v] = gs * (exp(z - lse[m]) - eps/V - (1 - eps) * [v == y[m]])
 __global__ __launch_bounds__(256) void ce_dlogits_bf16_kernel(const float* __restrict__ z, int ldl, const float* __restrict__ lse_in,
                                                                const int64_t* __restrict__ targets, int V, float eps, float gs,
@@ -133,6 +167,51 @@ extern "C" int capdec_cast_bf16_multi(const void* table_dev, int n, int total_bl
     hipLaunchKernelGGL(cast_bf16_multi_kernel, dim3((unsigned)total_blocks), dim3(256), 0, (hipStream_t)stream,
                        (const capdec_cast_desc*)table_dev, n);
     return check_launch("capdec_cast_bf16_multi");
+}
+
+extern "C" int capdec_copy_f32_multi_plan(capdec_cast_desc* descs, int n, void* table_dev, int* total_blocks) {
+    CAPDEC_REQUIRE(descs && table_dev && total_blocks && n > 0 && n <= CAPDEC_CAST_MULTI_MAX,
+                   "capdec_copy_f32_multi_plan: bad arguments (n=%d, at most %d matrices per table)", n, CAPDEC_CAST_MULTI_MAX);
+    int first = 0;
+    for (int i = 0; i < n; ++i) {
+        capdec_cast_desc& d = descs[i];
+        CAPDEC_REQUIRE(d.src && d.dst && d.R > 0 && d.C > 0 && d.lds >= d.C && d.ldd >= d.C,
+                       "capdec_copy_f32_multi_plan: matrix %d: bad R=%d C=%d lds=%d ldd=%d", i, d.R, d.C, d.lds, d.ldd);
+        const size_t groups = (size_t)d.R * ((d.C + 3) / 4);
+        size_t blocks = (groups + 1023) / 1024;  // four groups per thread
+        if (blocks > 4096) blocks = 4096;
+        d.vec = aligned16(d.src) && aligned16(d.dst) && d.lds % 4 == 0 && d.ldd % 4 == 0;
+        d.first_block = first;
+        d.blocks = (int)blocks;
+        d.reserved = 1;  // fp32 destination
+        first += (int)blocks;
+    }
+    *total_blocks = first;
+    if (hipMemcpy(table_dev, descs, (size_t)n * sizeof(capdec_cast_desc), hipMemcpyHostToDevice) != hipSuccess) {
+        set_error("capdec_copy_f32_multi_plan: copying the table to the device failed");
+        return CAPDEC_ERR_LAUNCH;
+    }
+    return 0;
+}
+
+extern "C" int capdec_copy_f32_multi(const void* table_dev, int n, int total_blocks, capdec_stream_t stream) {
+    CAPDEC_REQUIRE(table_dev && n > 0 && n <= CAPDEC_CAST_MULTI_MAX && total_blocks > 0,
+                   "capdec_copy_f32_multi: bad arguments (n=%d, total_blocks=%d)", n, total_blocks);
+    hipLaunchKernelGGL(copy_f32_multi_kernel, dim3((unsigned)total_blocks), dim3(256), 0, (hipStream_t)stream,
+                       (const capdec_cast_desc*)table_dev, n);
+    return check_launch("capdec_copy_f32_multi");
+}
+
+extern "C" int capdec_shift_captions(const int64_t* captions, int ld, int B, int T1, int64_t* tgt_in, int64_t* tgt_out,
+                                     capdec_stream_t stream) {
+    CAPDEC_REQUIRE(captions && tgt_in && tgt_out && B > 0 && T1 > 1 && ld >= T1, "capdec_shift_captions: bad arguments B=%d T1=%d ld=%d",
+                   B, T1, ld);
+    const size_t total = (size_t)B * (T1 - 1);
+    size_t blocks = (total + 255) / 256;
+    if (blocks > 4096) blocks = 4096;
+    hipLaunchKernelGGL(shift_captions_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, captions, ld, B, T1, tgt_in,
+                       tgt_out);
+    return check_launch("capdec_shift_captions");
 }
 
 extern "C" int capdec_ce_dlogits_bf16(const void* logits, int ldl, const void* lse, const int64_t* targets, int M, int V,

@@ -223,6 +223,12 @@ extern "C" int capdec_embed_fwd(const int64_t* ids, const void* E, const void* p
     return check_launch("capdec_embed_fwd");
 }
 
+namespace capdec {
+__global__ __launch_bounds__(256) void embed_zero_kernel(int* __restrict__ p, size_t n) {
+    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (size_t)gridDim.x * 256) p[i] = 0;
+}
+}  // namespace capdec
+
 extern "C" int capdec_embed_bad_ids(unsigned int* count, int reset) {
     CAPDEC_REQUIRE(count, "capdec_embed_bad_ids: null pointer");
     if (hipMemcpyFromSymbol(count, HIP_SYMBOL(g_bad_ids), sizeof(unsigned int)) != hipSuccess) {
@@ -267,10 +273,13 @@ extern "C" int capdec_embed_bwd_plan(const int64_t* ids, int B, int T, int d, in
     int* rank = offset + V + 1;
     int* order = rank + BT;
     hipStream_t st = (hipStream_t)stream;
-    // count [V], offset [V+1] and rank [BT] are contiguous: one memset zeroes the two accumulated arrays
-    if (hipMemsetAsync(count, 0, ((size_t)2 * V + 1 + BT) * sizeof(int), st) != hipSuccess) {
-        set_error("capdec_embed_bwd_plan: memset failed");
-        return CAPDEC_ERR_LAUNCH;
+    // count [V], offset [V+1] and rank [BT] are contiguous: one fill zeroes the two accumulated arrays (a kernel of this
+    // library rather than hipMemsetAsync: the step's trace then holds nothing but capdec kernels)
+    {
+        const size_t n = (size_t)2 * V + 1 + BT;
+        size_t zb = (n + 255) / 256;
+        if (zb > 1024) zb = 1024;
+        hipLaunchKernelGGL(embed_zero_kernel, dim3((unsigned)zb), dim3(256), 0, st, count, n);
     }
     const int nb = (BT + 255) / 256;
     hipLaunchKernelGGL(embed_rank_kernel, dim3(nb, nb), dim3(256), 0, st, ids, count, rank, BT, V);

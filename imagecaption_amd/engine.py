@@ -128,6 +128,17 @@ def layer_fwd(P, x, mem, B, T, S, H, causal, dp, l, save, kv=None):
     return x3
 
 
+def _zero_query_grads(G, gw, gb, d):
+    """The query rows of the cross-attention in-projection gradient are exactly zero over a one-position memory.  A
+    gradient dict whose rows are known to hold zeros already (a trainer's views of its flat block, which nothing else
+    writes: ``G["_cross_q_grads_zero"]``) is left alone -- no fill launches in the steady state."""
+    if not G.get("_cross_q_grads_zero", False):
+        gw[:d].zero_()
+        gb[:d].zero_()
+        if "_cross_q_grads_zero" in G:  # only dicts that carry the flag promise that nobody else writes these rows
+            G["_cross_q_grads_zero"] = True
+
+
 def layer_bwd(P, G, sv, dx3, mem, dmem, B, T, S, H, causal, dp, l, dkv=None):
     """Backward of layer_fwd.  Writes parameter grads into G[...] (overwrite); returns (dx, dmem).
     ``dkv``: a [B*S, 2d] row-strided view to receive dK | dV when the caller batches the d(memory) product
@@ -164,8 +175,7 @@ def layer_bwd(P, G, sv, dx3, mem, dmem, B, T, S, H, causal, dp, l, dkv=None):
             dkv = torch.empty_like(kv)
         # dk == 0 exactly (p = 1 for the only key), as torch computes it; dv = the head-diagonal of dvblk; bias gradient
         ops.cross1_gather(dvblk, dbp, dkv[:, :d], dkv[:, d:], G["multihead_attn.out_proj.bias"], B, H)
-        gw[:d].zero_()          # dq == 0 exactly: zero query-projection gradients, nothing flows to x1 through q
-        gb[:d].zero_()
+        _zero_query_grads(G, gw, gb, d)  # dq == 0 exactly: zero query-projection gradients, nothing flows to x1 through q
     else:
         ops.linear_wgrad(g2m, sv["c"], dw=G["multihead_attn.out_proj.weight"], db=G["multihead_attn.out_proj.bias"])
         dc = ops.linear_dgrad(g2m, P["multihead_attn.out_proj.weight"], out=_like16(sv["c"], g2m.shape[0], d))
@@ -175,9 +185,9 @@ def layer_bwd(P, G, sv, dx3, mem, dmem, B, T, S, H, causal, dp, l, dkv=None):
                                 dp.seed(sid + S_CA_P), dq=_like16(sv["q"], g2m.shape[0], d) if S != 1 else None,
                                 dk=dkv[:, :d], dv=dkv[:, d:], need_dq=S != 1)
         if S == 1:
-            gw[:d].zero_()
-            gb[:d].zero_()
+            _zero_query_grads(G, gw, gb, d)
         else:
+            G["_cross_q_grads_zero"] = False
             ops.linear_wgrad(dq, sv["x1"], dw=gw[:d], db=gb[:d])
     ops.linear_wgrad(dkv, mem, dw=gw[d:], db=gb[d:])
     if not batched:
@@ -203,16 +213,27 @@ def layer_bwd(P, G, sv, dx3, mem, dmem, B, T, S, H, causal, dp, l, dkv=None):
 # ---------------------------------------------------------------------------------------------
 # decoder stack (+ final norm), feature projection, output head
 # ---------------------------------------------------------------------------------------------
-def stack_fwd(layers, norm_w, norm_b, x, mem, B, T, S, H, causal, dp, save):
+def kv_batched(n_layers, mem_rows):
+    """Whether stack_fwd computes the cross-attention K | V projections of all layers as ONE product."""
+    return n_layers > 1 and mem_rows >= 1024
+
+
+def stack_fwd(layers, norm_w, norm_b, x, mem, B, T, S, H, causal, dp, save, kv_stack=None):
+    """``kv_stack``: (w_all [L*2d, d], b_all [L*2d]), the layers' cross-attention K | V projection weights / biases
+    already stacked (the trainer keeps such a block and refreshes it with one launch per step: ops.StackedRows);
+    None: concatenated here."""
     saves = [] if save is not None else None
     # The cross-attention K/V projections of all layers depend only on the memory: one GEMM with the layers'
     # weights stacked ([L*2d, d], a 6 MB gather at C2) instead of L mid-size ones; each layer reads its
     # [B*S, 2d] column block in place (the attention kernels take row strides).
     d = x.shape[1]
     kv_all = w_all = None
-    if len(layers) > 1 and mem.shape[0] >= 1024:
-        w_all = torch.cat([P["multihead_attn.in_proj_weight"][d:] for P in layers])
-        b_all = torch.cat([P["multihead_attn.in_proj_bias"][d:] for P in layers])
+    if kv_batched(len(layers), mem.shape[0]):
+        if kv_stack is not None:
+            w_all, b_all = kv_stack
+        else:
+            w_all = torch.cat([P["multihead_attn.in_proj_weight"][d:] for P in layers])
+            b_all = torch.cat([P["multihead_attn.in_proj_bias"][d:] for P in layers])
         # bf16 storage: the block exists only as bf16 (capdec_epilogue.c16) and the all-bf16 attention kernels stream it
         kv_all = ops.linear_fwd(mem, w_all, b_all, out=ops.bf16_matrix(mem.shape[0], w_all.shape[0], x.device)
                                 if _attn16(H, d) and S > 1 else None)
@@ -246,8 +267,10 @@ def stack_bwd(layers, grads, norm_w, norm_b, g_norm_w, g_norm_b, sv, dy, mem, B,
             # directly (no fp32 block, no cast pass); the padding columns of the pitch must read as zeros
             pitch = ops._bf16_pitch(w_all.shape[0])
             buf = torch.empty((mem.shape[0], pitch), dtype=torch.bfloat16, device=dy.device)
-            buf[:, w_all.shape[0]:].zero_()
-            dkv_all = ops._zero_padded(buf[:, :w_all.shape[0]])
+            dkv_all = buf[:, :w_all.shape[0]]
+            if w_all.shape[0] % 64:  # (a width that is a multiple of 64 has no reduction tail: the padding is never read)
+                buf[:, w_all.shape[0]:].zero_()
+                dkv_all = ops._zero_padded(dkv_all)
         else:
             dkv_all = torch.empty((mem.shape[0], w_all.shape[0]), dtype=torch.float32, device=dy.device)
     for l in range(len(layers) - 1, -1, -1):

@@ -128,6 +128,53 @@ class Bf16Copies:
         return {(t.data_ptr(), t.shape[0], t.shape[1], t.stride(0)): (t, c) for t, c in zip(self.sources, self.copies)}
 
 
+class StackedRows:
+    """One fp32 block [sum R_i, C] holding copies of matrices that live apart (row-strided fp32 views of equal width; a
+    [n] vector counts as [n, 1]), refreshed by ONE launch (capdec_copy_f32_multi): the trainer's stacked cross-attention
+    K | V projection weights and biases of all decoder layers, in place of a torch.cat per step."""
+
+    def __init__(self, sources):
+        if not 0 < len(sources) <= _capi.CAST_MULTI_MAX:
+            raise _capi.CapdecError(f"StackedRows: 1 .. {_capi.CAST_MULTI_MAX} matrices, got {len(sources)}")
+        vec = sources[0].dim() == 1
+        self.sources = [(_req(t, "StackedRows.src").unsqueeze(1) if vec else _mat(t, "StackedRows.src")) for t in sources]
+        cols = self.sources[0].shape[1]
+        if any(t.shape[1] != cols for t in self.sources):
+            raise _capi.CapdecError("StackedRows: matrices of different widths")
+        rows = sum(t.shape[0] for t in self.sources)
+        dev = self.sources[0].device
+        self.block = torch.empty((rows, cols), dtype=torch.float32, device=dev)
+        descs = (_capi.CastDesc * len(self.sources))()
+        r0 = 0
+        for d, t in zip(descs, self.sources):
+            dst = self.block[r0:r0 + t.shape[0]]
+            d.src, d.dst, d.lds, d.ldd, d.R, d.C = ptr(t), ptr(dst), t.stride(0), cols, t.shape[0], cols
+            r0 += t.shape[0]
+        self.table = torch.empty(C.sizeof(descs), dtype=torch.uint8, device=dev)
+        total = C.c_int(0)
+        check(lib().capdec_copy_f32_multi_plan(descs, len(self.sources), ptr(self.table), C.byref(total)),
+              "capdec_copy_f32_multi_plan")
+        self.total_blocks = total.value
+        self.view = self.block.view(-1) if vec else self.block
+
+    def refresh(self):
+        check(lib().capdec_copy_f32_multi(ptr(self.table), len(self.sources), self.total_blocks, stream()),
+              "capdec_copy_f32_multi")
+        return self.view
+
+
+def shift_captions(captions):
+    """(captions[:, :-1], captions[:, 1:]) as dense int64 blocks, one launch (ref train.py:29-30)."""
+    _req(captions, "shift_captions.captions", torch.int64)
+    if captions.dim() != 2 or captions.stride(1) != 1 or captions.shape[1] < 2:
+        raise _capi.CapdecError(f"shift_captions: need a [B, T + 1] int64 matrix with unit column stride, got {tuple(captions.shape)}")
+    B, T1 = captions.shape
+    out = torch.empty((2, B, T1 - 1), dtype=torch.int64, device=captions.device)
+    check(lib().capdec_shift_captions(ptr(captions), captions.stride(0), B, T1, ptr(out[0]), ptr(out[1]), stream()),
+          "capdec_shift_captions")
+    return out[0], out[1]
+
+
 class compute_dtype:
     """with ops.compute_dtype("bf16"): ...  -- scoped override of COMPUTE_DTYPE."""
 

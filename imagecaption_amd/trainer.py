@@ -124,6 +124,9 @@ class CaptionTrainer:
         m = self.model
         self.P_layers = [layer.param_dict() for layer in m.transformer_decoder.layers]
         self.G_layers = [{k: v.grad for k, v in P.items()} for P in self.P_layers]
+        for G in self.G_layers:  # these views are written by this trainer's launches only (engine._zero_query_grads)
+            G["_cross_q_grads_zero"] = False
+        self._kv_stack = None
         fp = m.feature_projection
         self.P_proj = dict(zip(engine.PROJ_KEYS, [fp[0].weight, fp[0].bias, fp[1].weight, fp[1].bias, fp[4].weight,
                                                   fp[4].bias, fp[5].weight, fp[5].bias]))
@@ -161,8 +164,7 @@ class CaptionTrainer:
 
     def _forward_backward(self, features, captions, train, keep_logits):
         m = self.model
-        tgt_in = captions[:, :-1].contiguous()   # ref train.py:29
-        tgt_out = captions[:, 1:].contiguous()   # ref train.py:30
+        tgt_in, tgt_out = ops.shift_captions(captions)   # ref train.py:29-30
         B, T = tgt_in.shape
         self._rows_guard.step(B * T)
         # each rank draws its own dropout masks (rank folded into the key): the same masks on different data would
@@ -188,8 +190,17 @@ class CaptionTrainer:
         mem = engine.proj_fwd(self.P_proj, f2, dp, sv_proj)
         x = ops.embed_fwd(tgt_in, m.embedding.weight, m.pos_encoder.table(), 0, dp.p, dp.seed(engine.S_EMBED))
         dec = m.transformer_decoder
+        kv_stack = None
+        if engine.kv_batched(self.nl, mem.shape[0]):
+            # the layers' cross-attention K | V weights and biases as one [L*2d, d] operand: a persistent block refreshed
+            # by ONE launch (the parameters live apart in the flat block, in state_dict order)
+            if self._kv_stack is None:
+                d = mem.shape[1]
+                self._kv_stack = (ops.StackedRows([P["multihead_attn.in_proj_weight"][d:] for P in self.P_layers]),
+                                  ops.StackedRows([P["multihead_attn.in_proj_bias"][d:] for P in self.P_layers]))
+            kv_stack = (self._kv_stack[0].refresh(), self._kv_stack[1].refresh())
         y = engine.stack_fwd(self.P_layers, dec.norm.weight, dec.norm.bias, x.view(B * T, -1), mem, B, T, S, self.nhead,
-                             True, dp, sv_stack)
+                             True, dp, sv_stack, kv_stack=kv_stack)
         # the logits block (B*T x V fp32, the step's largest tensor) is owned by the trainer: one allocation
         # for the run instead of a 100+ MB request to the caching allocator every step
         if self._logits is None or tuple(self._logits.shape) != (B * T, self.P_head["3.weight"].shape[0]):

@@ -149,6 +149,17 @@ typedef struct capdec_cast_desc {
     int vec, first_block, blocks, reserved; /* filled in by capdec_cast_bf16_multi_plan */
 } capdec_cast_desc;
 int capdec_cast_bf16_multi_plan(capdec_cast_desc* descs, int n, void* table_dev, int* total_blocks);
+/* capdec_copy_f32_multi: the same table mechanism for plain fp32 copies (dst fp32 [R, ldd], ldd >= C, nothing is padded):
+ * ONE launch gathers matrices that live apart into one block -- the cross-attention K | V projection weights and biases
+ * of all decoder layers (rows d..3d of each layer's multihead_attn.in_proj_weight / _bias, ref models.py:53-65 through
+ * torch/nn/modules/activation.py) stacked into the [L*2d, d] operand of the batched K | V product, in place of a
+ * torch.cat per step. */
+int capdec_copy_f32_multi_plan(capdec_cast_desc* descs, int n, void* table_dev, int* total_blocks);
+int capdec_copy_f32_multi(const void* table_dev, int n, int total_blocks, capdec_stream_t stream);
+/* tgt_in = captions[:, :-1], tgt_out = captions[:, 1:] (ref train.py:29-30) as two dense int64 [B, T1 - 1] blocks in one
+ * launch; captions [B, T1] with row stride ld. */
+int capdec_shift_captions(const int64_t* captions, int ld, int B, int T1, int64_t* tgt_in, int64_t* tgt_out,
+                          capdec_stream_t stream);
 int capdec_cast_bf16_multi(const void* table_dev, int n, int total_blocks, capdec_stream_t stream);
 int capdec_ce_dlogits_bf16(const void* logits, int ldl, const void* lse, const int64_t* targets, int M, int V,
                            float eps, float grad_scale, void* dst, int ldd, capdec_stream_t stream);

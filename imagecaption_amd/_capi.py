@@ -30,6 +30,14 @@ class CastDesc(C.Structure):
 
 
 CAST_MULTI_MAX = 256
+GEMM_GROUP_MAX = 8
+
+
+class GemmDesc(C.Structure):
+    """capdec_gemm_desc of include/capdec.h."""
+    _fields_ = [("transA", _i), ("transB", _i), ("M", _i), ("N", _i), ("K", _i), ("A", _vp), ("lda", _i), ("B", _vp),
+                ("ldb", _i), ("C", _vp), ("ldc", _i), ("ep", C.POINTER(Epilogue))]
+
 
 # name -> (restype, argtypes); mirrors include/capdec.h one to one
 SIGNATURES = {
@@ -40,6 +48,7 @@ SIGNATURES = {
     "capdec_gemm_plan_set": (_i, [_i, _i, _i, _i, _i, _i, _i, _i, _i, _i]),
     "capdec_gemm_plan_clear": (None, []),
     "capdec_gemm": (_i, [_i, _i, _i, _i, _i, _vp, _i, _vp, _i, _vp, _i, C.POINTER(Epilogue), _i, _vp, _sz, _vp]),
+    "capdec_gemm_grouped": (_i, [C.POINTER(GemmDesc), _i, _i, _i, _vp]),
     "capdec_layernorm_bwd_workspace_bytes": (_sz, [_i, _i]),
     "capdec_layernorm2_fwd": (_i, [_vp, _vp, _vp, _vp, _i, _vp, _vp, _vp, _i, _i, _f, _vp]),
     "capdec_layernorm_fwd": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _f, _i, _f, _u64, _vp]),

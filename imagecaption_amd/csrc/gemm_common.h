@@ -37,6 +37,14 @@ struct GemmParams {
     int ldc2, n_split;
 };
 
+// capdec_gemm_grouped: the products of one launch, passed by value (kernel arguments)
+struct GemmGroupParams {
+    int n;
+    int first[CAPDEC_GEMM_GROUP_MAX];   // first workgroup of product i (a multiple of 8)
+    int tiles[CAPDEC_GEMM_GROUP_MAX];   // its tile count; the workgroups between first + tiles and the next first are idle
+    GemmParams p[CAPDEC_GEMM_GROUP_MAX];
+};
+
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 
 constexpr int GEMM_SPLITK_MAX_TILES = 4096;                       // arrival counters at the head of the workspace

@@ -61,9 +61,11 @@ constexpr int gemm_f32_waves(int bm, int bn, int bk) {
 
 // CE: the A loaders read LOGITS and turn them into cross-entropy gradients on their way into LDS (see
 // gemm_common.h); a template flag so that the plain instantiations carry none of its registers.
+// One BM x BN output tile (and K slice blockIdx.z) of one product: the body of gemm_f32_kernel, and of
+// gemm_f32_grouped_kernel, whose workgroups each pick a product from a table first.  wg_raw / nwg: this workgroup's
+// number among the product's nwg tiles (wg_raw & 7 = the XCD it runs on, for the tile order).
 template <int BM, int BN, int GBK, bool AK, bool BKM, bool VEC, bool CE = false>
-__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(gemm_f32_waves(BM, BN, GBK))))
-void gemm_f32_kernel(GemmParams p) {
+__device__ __forceinline__ void gemm_f32_tile(const GemmParams& p, const int wg_raw, const int nwg) {
     constexpr int NT = 256;
     constexpr int TM = BM / 64, TN = BN / 64;  // 32x32 accumulators per wave in each direction
     constexpr int A_LD = AK ? (BM + 2) * 4 : (BM + 4);  // floats per k-quad (AK) or per k (row-contig)
@@ -82,8 +84,7 @@ void gemm_f32_kernel(GemmParams p) {
 
     // XCD-aware tile order: blocks b and b+8 share an XCD (round-robin dispatch), so give each XCD
     // a contiguous run of tiles (neighbouring tiles share an A row panel in that XCD's L2).
-    const int nwg = gridDim.x;
-    int wg = blockIdx.x;
+    int wg = wg_raw;
     {
         const int q = nwg >> 3, r = nwg & 7, xcd = wg & 7;
         wg = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (wg >> 3);
@@ -299,6 +300,30 @@ void gemm_f32_kernel(GemmParams p) {
     epilogue_store<TM, TN>(p, acc, m0 + wrow, n0 + wcol, l31, half);
 }
 
+template <int BM, int BN, int GBK, bool AK, bool BKM, bool VEC, bool CE = false>
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(gemm_f32_waves(BM, BN, GBK))))
+void gemm_f32_kernel(GemmParams p) {
+    gemm_f32_tile<BM, BN, GBK, AK, BKM, VEC, CE>(p, blockIdx.x, gridDim.x);
+}
+
+// Several independent products of one layout in ONE launch (capdec_gemm_grouped): workgroup b belongs to the product
+// whose block range [first[g], first[g + 1]) holds b (ranges start at multiples of 8, so a workgroup's number inside
+// its product keeps the XCD parity the tile order relies on; the few padding workgroups of a range leave at once).
+// Small products -- a decoder layer's weight gradients: 64 - 256 tiles each, which alone need split-K and its slab
+// round trips to fill 256 CUs -- then run unsplit as one chip-filling grid.
+template <int BM, int BN, int GBK, bool AK, bool BKM>
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(gemm_f32_waves(BM, BN, GBK))))
+void gemm_f32_grouped_kernel(GemmGroupParams g) {
+    int i = 0;
+#pragma unroll
+    for (int k = 1; k < CAPDEC_GEMM_GROUP_MAX; ++k)
+        if (k < g.n && (int)blockIdx.x >= g.first[k]) i = k;
+    const int local = (int)blockIdx.x - g.first[i];
+    const int tiles = g.tiles[i];
+    if (local >= tiles) return;
+    gemm_f32_tile<BM, BN, GBK, AK, BKM, true>(g.p[i], local, tiles);
+}
+
 // ---- host side: tile / split-K choice ---------------------------------------------------------
 // MFMA-bound cost model, calibrated on tools/gemm_sweep.py (profiles/r01_gemm_sweep.txt).  A CU
 // with r co-resident workgroups runs r waves per SIMD; one wave per SIMD cannot cover its own
@@ -423,6 +448,81 @@ extern "C" size_t capdec_gemm_workspace_bytes(int M, int N, int K) {
                 if (b > need) need = b;
             }
     return need;
+}
+
+// fill GemmParams from the public arguments (shared by capdec_gemm's checks below and capdec_gemm_grouped)
+static void fill_params(GemmParams& p, int M, int N, int K, const void* A, int lda, const void* B, int ldb, void* C, int ldc,
+                        const capdec_epilogue* ep) {
+    memset(&p, 0, sizeof(p));
+    p.A = (const float*)A;
+    p.B = (const float*)B;
+    p.C = (float*)C;
+    p.M = M; p.N = N; p.K = K; p.lda = lda; p.ldb = ldb; p.ldc = ldc;
+    p.drop = make_dropout(0.f, 0);
+    if (ep) {
+        p.bias = (const float*)ep->bias;
+        p.addend = (const float*)ep->addend;
+        p.pre = (float*)ep->pre;
+        p.aux = (const float*)ep->aux;
+        p.colsum = (float*)ep->colsum;
+        p.ld_addend = ep->ld_addend;
+        p.act = ep->act;
+        p.drop = make_dropout(ep->drop_p, ep->drop_seed);
+    }
+}
+
+template <int BM, int BN, int BK>
+static void launch_grouped(const GemmGroupParams& g, bool AK, bool BKM, int blocks, hipStream_t st) {
+    const dim3 grid(blocks), block(256);
+    if (AK && BKM) hipLaunchKernelGGL((gemm_f32_grouped_kernel<BM, BN, BK, true, true>), grid, block, 0, st, g);
+    else if (AK && !BKM) hipLaunchKernelGGL((gemm_f32_grouped_kernel<BM, BN, BK, true, false>), grid, block, 0, st, g);
+    else if (!AK && !BKM) hipLaunchKernelGGL((gemm_f32_grouped_kernel<BM, BN, BK, false, false>), grid, block, 0, st, g);
+    else hipLaunchKernelGGL((gemm_f32_grouped_kernel<BM, BN, BK, false, true>), grid, block, 0, st, g);
+}
+
+extern "C" int capdec_gemm_grouped(const capdec_gemm_desc* descs, int n, int bm, int bn, capdec_stream_t stream) {
+    CAPDEC_REQUIRE(descs && n > 0 && n <= CAPDEC_GEMM_GROUP_MAX, "capdec_gemm_grouped: 1 .. %d products per launch, got %d",
+                   CAPDEC_GEMM_GROUP_MAX, n);
+    CAPDEC_REQUIRE((bm == 0 && bn == 0) || ((bm == 64 || bm == 128) && (bn == 64 || bn == 128)),
+                   "capdec_gemm_grouped: tile %dx%d not in {64,128}^2 (0, 0 = default)", bm, bn);
+    if (bm == 0) bm = bn = 64;
+    GemmGroupParams g;
+    memset(&g, 0, sizeof(g));
+    g.n = n;
+    int first = 0;
+    const int ta = descs[0].transA != 0, tb = descs[0].transB != 0;
+    for (int i = 0; i < n; ++i) {
+        const capdec_gemm_desc& d = descs[i];
+        CAPDEC_REQUIRE((d.transA != 0) == ta && (d.transB != 0) == tb, "capdec_gemm_grouped: product %d has another layout than product 0", i);
+        CAPDEC_REQUIRE(d.M > 0 && d.N > 0 && d.K > 0 && d.A && d.B && d.C, "capdec_gemm_grouped: product %d: bad shape / null operand", i);
+        CAPDEC_REQUIRE(d.lda >= (ta ? d.M : d.K) && d.ldb >= (tb ? d.K : d.N) && d.ldc >= d.N,
+                       "capdec_gemm_grouped: product %d: leading dimension too small", i);
+        CAPDEC_REQUIRE(aligned16(d.A) && aligned16(d.B) && d.lda % 4 == 0 && d.ldb % 4 == 0,
+                       "capdec_gemm_grouped: product %d: operands must be 16-byte aligned with leading dimensions that are multiples of 4", i);
+        const capdec_epilogue* ep = d.ep;
+        CAPDEC_REQUIRE(!ep || (!ep->ce_partials && !ep->ce_lse && !ep->c16), "capdec_gemm_grouped: product %d: no cross-entropy fusion / bf16 result here", i);
+        CAPDEC_REQUIRE(!ep || ep->act != CAPDEC_ACT_GELU_BWD || ep->aux, "capdec_gemm_grouped: product %d: ACT_GELU_BWD needs aux", i);
+        CAPDEC_REQUIRE(!ep || !ep->colsum || ta, "capdec_gemm_grouped: product %d: colsum needs transA=1", i);
+        CAPDEC_REQUIRE(!ep || !ep->addend || ep->ld_addend >= d.N, "capdec_gemm_grouped: product %d: ld_addend too small", i);
+        CAPDEC_REQUIRE(!ep || (ep->drop_p >= 0.f && ep->drop_p < 1.f), "capdec_gemm_grouped: product %d: drop_p out of range", i);
+        CAPDEC_REQUIRE(!(ep && ep->drop_p > 0.f) || (uint64_t)d.M * (uint64_t)d.N < (1ull << 32),
+                       "capdec_gemm_grouped: product %d: M*N exceeds 2^32 with dropout in the epilogue", i);
+        fill_params(g.p[i], d.M, d.N, d.K, d.A, d.lda, d.B, d.ldb, d.C, d.ldc, ep);
+        g.p[i].ksplit = d.K;  // unsplit
+        g.p[i].tiles_n = cdiv(d.N, bn);
+        const long tiles = (long)cdiv(d.M, bm) * g.p[i].tiles_n;
+        CAPDEC_REQUIRE(tiles + first < (1l << 30), "capdec_gemm_grouped: too many tiles");
+        g.first[i] = first;
+        g.tiles[i] = (int)tiles;
+        first += ((int)tiles + 7) / 8 * 8;
+    }
+    hipStream_t st = (hipStream_t)stream;
+    const bool AK = !ta, BKM = tb;
+    if (bm == 128 && bn == 128) launch_grouped<128, 128, 16>(g, AK, BKM, first, st);
+    else if (bm == 128 && bn == 64) launch_grouped<128, 64, 16>(g, AK, BKM, first, st);
+    else if (bm == 64 && bn == 128) launch_grouped<64, 128, 16>(g, AK, BKM, first, st);
+    else launch_grouped<64, 64, 16>(g, AK, BKM, first, st);
+    return check_launch("capdec_gemm_grouped");
 }
 
 extern "C" int capdec_gemm(int transA, int transB, int M, int N, int K, const void* A, int lda, const void* B,

@@ -168,17 +168,44 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(const float* __restrict__ d
         for (int j = 0; j < 4; ++j) dg[i][j] = db[i][j] = 0.f;
     }
     const float inv_d = 1.0f / (float)d;
+    // one row ahead: a wave walks 2 - 3 rows here (grid-stride) and each row is two dependent round trips to memory
+    // (loads, then the stores behind two wave reductions); with the NEXT row's loads issued before this row's
+    // arithmetic the walk costs one exposed latency, not one per row
+    float4 nx[NV], nd[NV];
+    float nmean = 0.f, nrstd = 0.f;
+    auto fetch = [&](int row) {
+        if (row < M) {
+            nmean = mean_in[row];
+            nrstd = rstd_in[row];
+            const float4* xr = reinterpret_cast<const float4*>(x + (size_t)row * d);
+            const float4* dyr = reinterpret_cast<const float4*>(dy + (size_t)row * d);
+#pragma unroll
+            for (int i = 0; i < NV; ++i) {
+                const int q = lane + 64 * i;
+                if (q < nq) {
+                    nx[i] = xr[q];
+                    nd[i] = dyr[q];
+                }
+            }
+        }
+    };
+    fetch(blockIdx.x * 4 + wave);
     for (int row = blockIdx.x * 4 + wave; row < M; row += gridDim.x * 4) {
-        const float mean = mean_in[row], rstd = rstd_in[row];
-        const float4* xr = reinterpret_cast<const float4*>(x + (size_t)row * d);
-        const float4* dyr = reinterpret_cast<const float4*>(dy + (size_t)row * d);
+        const float mean = nmean, rstd = nrstd;
+        float4 cx[NV], cd[NV];
+#pragma unroll
+        for (int i = 0; i < NV; ++i) {
+            cx[i] = nx[i];
+            cd[i] = nd[i];
+        }
+        fetch(row + gridDim.x * 4);
         float xh[NV][4], g[NV][4];
         float s1 = 0.f, s2 = 0.f;
 #pragma unroll
         for (int i = 0; i < NV; ++i) {
             const int q = lane + 64 * i;
             if (q < nq) {
-                const float4 xv = xr[q], dv = dyr[q];
+                const float4 xv = cx[i], dv = cd[i];
                 const float xa[4] = {xv.x, xv.y, xv.z, xv.w};
                 float da[4] = {dv.x, dv.y, dv.z, dv.w};
                 const float ga[4] = {gm[i].x, gm[i].y, gm[i].z, gm[i].w};

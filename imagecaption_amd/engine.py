@@ -206,6 +206,7 @@ def layer_bwd(P, G, sv, dx3, mem, dmem, B, T, S, H, causal, dp, l, dkv=None):
     ops.attn_bwd(qkv[:, :d], qkv[:, d:2 * d], qkv[:, 2 * d:], sv["a"], da, sv["lse1"], B, H, T, T, causal, p,
                  dp.seed(sid + S_SA_P), dq=dqkv[:, :d], dk=dqkv[:, d:2 * d], dv=dqkv[:, 2 * d:])
     ops.linear_wgrad(dqkv, sv["x"], dw=G["self_attn.in_proj_weight"], db=G["self_attn.in_proj_bias"])
+    ops.wgrad_flush()  # the layer's weight gradients: one grouped launch on the side lane (ops.GROUP_WGRADS)
     dx = ops.linear_dgrad(dqkv, P["self_attn.in_proj_weight"], addend=g1)
     return dx, dmem
 
@@ -307,6 +308,7 @@ def proj_bwd(P, G, sv, dmem, dp, want_df=False):
                                       want_dx_drop=d16, dx_drop16=d16)
     g1 = g1c if d16 else g1
     ops.linear_wgrad(g1, sv["f"], dw=G["0.weight"], db=G["0.bias"])
+    ops.wgrad_flush()
     return ops.linear_dgrad(g1, P["0.weight"]) if want_df else None
 
 
@@ -331,4 +333,5 @@ def head_bwd(P, G, sv, dlogits, dp, ce=None):
     du = ops.linear_dgrad(dlogits, P["3.weight"], gelu_pre=sv["u"], drop_p=dp.p, seed=dp.seed(S_HEAD), ce=ce,
                           out=_like16(sv["h"], *sv["h"].shape))
     ops.linear_wgrad(du, sv["x"], dw=G["0.weight"], db=G["0.bias"])
+    ops.wgrad_flush()
     return ops.linear_dgrad(du, P["0.weight"])

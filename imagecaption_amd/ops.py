@@ -299,6 +299,7 @@ class SideStream:
         self.pending = True
 
     def join(self):
+        wgrad_flush()
         if self.pending:
             torch.cuda.current_stream().wait_stream(self.stream)
             self.keep.clear()
@@ -525,11 +526,76 @@ def linear_dgrad(dy, w, out=None, addend=None, gelu_pre=None, drop_p=0.0, seed=0
     return gemm(dy, w, False, False, out=out, addend=addend, aux=gelu_pre, act=act, drop_p=drop_p, seed=seed, ce=ce)
 
 
+# ---- grouped weight gradients --------------------------------------------------------------------------------------
+# The weight gradients of a decoder layer are small products (64 - 256 output tiles each) that are all ready by the end
+# of the layer's backward and that nothing needs before the optimizer: with GROUP_WGRADS on, linear_wgrad only queues
+# them (exact fp32, side lane active, caller-owned outputs) and wgrad_flush() -- called by the engine at the end of a
+# block's backward -- launches up to GEMM_GROUP_MAX of them as ONE chip-filling, unsplit grid (capdec_gemm_grouped).
+GROUP_WGRADS = os.environ.get("CAPDEC_GROUP_WGRADS", "1") == "1"
+GROUP_TILE = (0, 0)   # block tile of the grouped launches ((0, 0) = the library's default, 64 x 64)
+_WGRAD_QUEUE = []
+
+
+def gemm_grouped(products, tile=(0, 0)):
+    """``products``: [(a, b, trans_a, trans_b, out, colsum)], fp32 matrices, one layout -- one launch (capdec_gemm_grouped)."""
+    n = len(products)
+    descs = (_capi.GemmDesc * n)()
+    eps = (_capi.Epilogue * n)()
+    flops = 0.0
+    for d, ep, (a, b, ta, tb, out, colsum) in zip(descs, eps, products):
+        _mat(a, "gemm_grouped.a"), _mat(b, "gemm_grouped.b"), _mat(out, "gemm_grouped.out")
+        M, K = (a.shape[1], a.shape[0]) if ta else (a.shape[0], a.shape[1])
+        Kb, N = (b.shape[1], b.shape[0]) if tb else (b.shape[0], b.shape[1])
+        if K != Kb or tuple(out.shape) != (M, N) or (colsum is not None and colsum.numel() != M):
+            raise _capi.CapdecError(f"gemm_grouped: shapes {tuple(a.shape)} x {tuple(b.shape)} -> {tuple(out.shape)} do not fit")
+        ep.colsum = ptr(colsum)
+        d.transA, d.transB, d.M, d.N, d.K = int(ta), int(tb), M, N, K
+        d.A, d.lda, d.B, d.ldb, d.C, d.ldc = ptr(a), a.stride(0), ptr(b), b.stride(0), ptr(out), out.stride(0)
+        d.ep = C.pointer(ep)
+        flops += 2.0 * M * N * K
+    args = (descs, n, int(tile[0]), int(tile[1]), stream())
+    if PROFILE is None:
+        check(lib().capdec_gemm_grouped(*args), "capdec_gemm_grouped")
+        return
+    with _Timed(f"gemm_grouped_{n}", flops):
+        check(lib().capdec_gemm_grouped(*args), "capdec_gemm_grouped")
+
+
+def _groupable(t):
+    return t.dtype == torch.float32 and t.dim() == 2 and t.stride(1) == 1 and t.stride(0) % 4 == 0 and t.data_ptr() % 16 == 0
+
+
+def wgrad_flush():
+    """Launch the queued weight gradients (grouped by GEMM_GROUP_MAX) on the side lane."""
+    global _WGRAD_QUEUE
+    if not _WGRAD_QUEUE:
+        return
+    q, _WGRAD_QUEUE = _WGRAD_QUEUE, []
+    if SIDE is None:  # (the lane went away between queueing and flushing: run them here)
+        for dy, x, dw, db in q:
+            gemm(dy, x, True, False, out=dw, colsum=db)
+        return
+    # longest reductions first: their tiles start first and the short ones fill the tail of the launch
+    q.sort(key=lambda e: -e[0].shape[0])
+    for i in range(0, len(q), _capi.GEMM_GROUP_MAX):
+        part = q[i:i + _capi.GEMM_GROUP_MAX]
+        if len(part) == 1:
+            dy, x, dw, db = part[0]
+            SIDE.run(lambda: gemm(dy, x, True, False, out=dw, colsum=db), dy, x)
+        else:
+            SIDE.run(lambda: gemm_grouped([(dy, x, True, False, dw, db) for dy, x, dw, db in part], GROUP_TILE),
+                     *[t for e in part for t in e[:2]])
+
+
 def linear_wgrad(dy, x, dw=None, db=None, ce=None):
     """dw[N,K] = dy.T @ x, db[N] = column sums of dy (fused into the same kernel).  ``ce``: see gemm (dy = logits).
 
     With a SideStream active and caller-owned outputs, the product is enqueued on the side stream
     (ordered after everything enqueued so far on the current stream) and the call returns at once."""
+    if SIDE is not None and dw is not None and GROUP_WGRADS and COMPUTE_DTYPE == F32 and ce is None and TUNE_RECORD is None \
+            and _groupable(dy) and _groupable(x) and _groupable(dw):
+        _WGRAD_QUEUE.append((dy, x, dw, db))
+        return dw
     if SIDE is not None and dw is not None:
         if COMPUTE_DTYPE == _capi.BF16S:  # bf16 copies are made (or found) on the caller's stream, not on the lane
             dy, x = _bf16_operand(dy, "linear_wgrad.dy"), _bf16_operand(x, "linear_wgrad.x")

@@ -124,6 +124,24 @@ int capdec_gemm(int transA, int transB, int M, int N, int K, const void* A, int 
                 void* C, int ldc, const capdec_epilogue* ep, int dtype, void* workspace, size_t workspace_bytes,
                 capdec_stream_t stream);
 
+/* capdec_gemm_grouped: up to CAPDEC_GEMM_GROUP_MAX INDEPENDENT exact-fp32 products of one layout (equal transA /
+ * transB) in ONE launch, each with capdec_gemm's arguments and epilogue (bias, activation, dropout, residual, pre, aux,
+ * colsum; no cross-entropy fusion, no bf16 result), operands 16-byte aligned with leading dimensions that are
+ * multiples of 4.  For sets of small products that are ready at the same time -- the weight gradients of one decoder
+ * layer (dW = dY^T X of torch/nn/modules/transformer.py:1143-1199's seven linear maps, 64 - 256 output tiles each): one
+ * by one they need split-K with its slab round trips to occupy 256 CUs; together they are one chip-filling unsplit
+ * grid.  bm x bn in {64,128}^2 is the block tile (0, 0 = 64 x 64).  Every product's K sum runs in one piece: results
+ * are bit-identical to capdec_gemm under a forced unsplit plan of the same tile, deterministic, no workspace. */
+#define CAPDEC_GEMM_GROUP_MAX 8
+typedef struct capdec_gemm_desc {
+    int transA, transB, M, N, K;
+    const void* A; int lda;
+    const void* B; int ldb;
+    void* C; int ldc;
+    const capdec_epilogue* ep; /* may be NULL */
+} capdec_gemm_desc;
+int capdec_gemm_grouped(const capdec_gemm_desc* descs, int n, int bm, int bn, capdec_stream_t stream);
+
 /* ---- bf16 copies for CAPDEC_BF16S products ----------------------------------------------------------------
  * capdec_cast_bf16: dst[r][c] = bf16(src[r][c]) (round to nearest even) for an fp32 matrix [R, C] with row stride
  * lds; dst has row stride ldd (bf16 elements, a multiple of 8, >= C) and its padding columns C .. ldd-1 are

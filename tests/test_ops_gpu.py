@@ -231,6 +231,46 @@ def test_pe_add_seq_first():
     assert torch.equal(out.cpu(), x + pe[:T].unsqueeze(1))
 
 
+@pytest.mark.parametrize("ta,tb", [(1, 0), (0, 1), (0, 0), (1, 1)])
+@pytest.mark.parametrize("tile", [(0, 0), (128, 64), (128, 128)])
+def test_grouped_gemm_equals_the_single_products_bit_for_bit(ta, tb, tile):
+    """capdec_gemm_grouped (several independent products of one layout in one launch; a decoder layer's weight
+    gradients) against capdec_gemm under the same tile, unsplit: identical bits, bias-gradient column sums included;
+    ragged shapes, row-strided operands, a product smaller than one tile, eight products per launch."""
+    ops = _ops()
+    from imagecaption_amd import _capi
+    l = _capi.lib()
+    g = torch.Generator().manual_seed(17 + 2 * ta + tb)
+    shapes = [(512, 512, 640), (192, 64, 1000), (70, 130, 333), (1, 5, 4), (256, 2048, 128), (64, 64, 64), (130, 70, 2048),
+              (33, 257, 65)]
+    prods, singles = [], []
+    for M, N, K in shapes:
+        r4 = lambda n: (n + 3) // 4 * 4 + 4   # row-strided views; leading dimensions stay multiples of 4
+        a = torch.randn((K, r4(M)) if ta else (M, r4(K)), generator=g).to(DEV)[:, :(M if ta else K)]
+        b = torch.randn((N, r4(K)) if tb else (K, r4(N)), generator=g).to(DEV)[:, :(K if tb else N)]
+        out = torch.full((M, N), float("nan"), device=DEV)
+        cs = torch.full((M,), float("nan"), device=DEV) if ta else None
+        prods.append((a, b, ta, tb, out, cs))
+    ops.gemm_grouped(prods, tile)
+    bm, bn = tile if tile[0] else (64, 64)
+    try:
+        l.capdec_gemm_tune(bm, bn, 1, 16)
+        for a, b, _, _, out, cs in prods:
+            cs1 = torch.empty_like(cs) if cs is not None else None
+            singles.append((ops.gemm(a, b, ta, tb, colsum=cs1), cs1))
+    finally:
+        l.capdec_gemm_tune(0, 0, 0, 0)
+    for (a, b, _, _, out, cs), (ref, cs1) in zip(prods, singles):
+        assert torch.equal(out, ref), tuple(out.shape)
+        if cs is not None:
+            assert torch.equal(cs, cs1)
+        a64, b64 = a.double().cpu(), b.double().cpu()
+        exact = (a64.T if ta else a64) @ (b64.T if tb else b64)
+        assert relerr(out, exact) < 2e-6 * math.sqrt(a.shape[0] if ta else a.shape[1])
+    with pytest.raises(_capi.CapdecError):  # mixed layouts are refused
+        ops.gemm_grouped([prods[0], (prods[1][0], prods[1][1], 1 - ta, tb, prods[1][4], None)])
+
+
 # ---------------------------------------------------------------------------------------------
 def _attn_ref(q, k, v, H, causal):
     B, Tq, D = q.shape

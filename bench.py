@@ -258,22 +258,26 @@ def profile_step(trainer, feats, ids, reps=3):
     return agg, detail
 
 
-def measured_hbm_copy_gbs():
-    """Read + write rate of a streaming copy of 1 GiB on THIS box (csrc/probe.hip), GB/s: what an
-    HBM-bound kernel can reach here, next to the nominal 8 TB/s the roofline fractions are quoted on."""
+def measured_hbm_copy_gbs(n=1 << 30):
+    """Read + write rate of a streaming copy of ``n`` bytes on THIS box (csrc/probe.hip), GB/s: what an HBM-bound
+    kernel can reach here, next to the nominal 8 TB/s the roofline fractions are quoted on.  1 GiB streams from HBM;
+    a copy of a launch's own working set (tens of MiB) runs out of the 256 MiB Infinity Cache, as the attention
+    launches of a step do."""
     from imagecaption_amd._capi import check, lib, ptr, stream
-    n = 1 << 30
+    n = max(1 << 20, int(n) // 256 * 256)
     src = torch.empty(n, dtype=torch.uint8, device="cuda")
     dst = torch.empty(n, dtype=torch.uint8, device="cuda")
     src.zero_()
     best = 0.0
+    reps = 1 if n >= (1 << 28) else 8  # short copies: several launches between the events
     for _ in range(3):
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         e0.record()
-        check(lib().capdec_probe_copy(ptr(src), ptr(dst), n, stream()), "capdec_probe_copy")
+        for _ in range(reps):
+            check(lib().capdec_probe_copy(ptr(src), ptr(dst), n, stream()), "capdec_probe_copy")
         e1.record()
         torch.cuda.synchronize()
-        best = max(best, 2.0 * n / (e0.elapsed_time(e1) * 1e-3) / 1e9)
+        best = max(best, 2.0 * n * reps / (e0.elapsed_time(e1) * 1e-3) / 1e9)
     return best
 
 
@@ -334,13 +338,20 @@ def roofline_block(cfg, dtype, agg, detail, traffic=None, with_peaks=True):
            "launches_per_step": sum(a[0] for a in attn.values())}
     if with_peaks:
         att["peak_measured"] = measured_hbm_copy_gbs()
+        # the ceiling for THESE launches: a copy that moves as many bytes as the average attention launch (read + write
+        # together), i.e. of half that size -- tens of MiB, served by the Infinity Cache between launches
+        n_launch = sum(a[0] for a in attn.values())
+        if n_launch:
+            att["bytes_per_launch"] = attn_b / n_launch
+            att["peak_measured_working_set"] = measured_hbm_copy_gbs(attn_b / n_launch / 2)
+            att["frac_of_working_set_copy"] = att["achieved"] / att["peak_measured_working_set"]
     return {"roofline": roof,
             "gemm_all": {"bound": "mfma", "achieved": ach, "peak": peak, "unit": "TFLOP/s", "frac": ach / peak,
                          "launches_per_step": gemm_n, "ms_per_step": gemm_time * 1e3},
             "attention": att}
 
 
-def run_leg(name, dtype, steps, warmup, dev, rank, world, args):
+def run_leg(name, dtype, steps, warmup, dev, rank, world, args, decode_images=0):
     """Another BASELINE configuration timed by the same harness (its own model, trainer, measured GEMM plans and
     roofline); never the headline `value`."""
     from imagecaption_amd import ImageCaptioningModel
@@ -370,9 +381,18 @@ def run_leg(name, dtype, steps, warmup, dev, rank, world, args):
                       "memory_len": cfg["S"]},
            "step_tflops_algorithmic": train_flops_per_image(cfg) * value / 1e12}
     out.update(roofline_block(cfg, dtype, agg, detail, with_peaks=False))
+    dec = None
+    if decode_images:
+        # decoding at this leg's dimensions (fp32, as the headline's decode numbers): for C3 the 30 000-word vocabulary
+        # projection and beam selection (BASELINE configs[4]-style decoding on the large-vocabulary shape)
+        del tr
+        torch.cuda.empty_cache()
+        dec = decode_bench(model, cfg, dev, rank, world, dtype="fp32", images=decode_images, max_len=cfg["T"])
+        dec["config"] = {"workload": LEG_WORKLOADS[name].split(":")[0] + " dimensions, KV-cached decode, fp32", "beam": [3, 5]}
+        tr = None
     del tr, model
     torch.cuda.empty_cache()
-    return out
+    return (out, dec) if decode_images else out
 
 
 LEG_WORKLOADS = {
@@ -462,6 +482,7 @@ def main():
     ap.add_argument("--detail", action="store_true", help="print the per-shape kernel table to stderr")
     ap.add_argument("--modes", default="f32x3,bf16,bf16s", help="the optional arithmetic modes timed after the fp32 run")
     ap.add_argument("--no-modes", action="store_true", help="skip the f32x3 / bf16 / bf16s legs of the default fp32 run")
+    ap.add_argument("--c3-decode-images", type=int, default=2048, help="images per GPU of the C3-dimension decode leg")
     ap.add_argument("--no-legs", action="store_true", help="skip the C1 (fp32) and C3 (bf16) legs of the default run")
     ap.add_argument("--cpu-full", action="store_true", help="CPU baseline also for C3 (3 steps) and beam-5 (256 images): minutes")
     ap.add_argument("--no-tune", action="store_true", help="keep the cost model's GEMM plans (skip the measured-plan set-up)")
@@ -554,7 +575,11 @@ def main():
     legs = {}
     if args.config == "c2" and args.dtype == "fp32" and not args.no_legs and world == 1:
         legs["c1_fp32"] = run_leg("c1", "fp32", max(5, args.steps // 2), 3, dev, rank, world, args)
-        legs["c3_bf16"] = run_leg("c3", "bf16s", max(5, args.steps // 2), 3, dev, rank, world, args)
+        if args.no_decode:
+            legs["c3_bf16"] = run_leg("c3", "bf16s", max(5, args.steps // 2), 3, dev, rank, world, args)
+        else:
+            legs["c3_bf16"], legs["c3_decode"] = run_leg("c3", "bf16s", max(5, args.steps // 2), 3, dev, rank, world, args,
+                                                         decode_images=args.c3_decode_images)
     out = None
     if rank == 0:
         ms = dt / args.steps * 1e3

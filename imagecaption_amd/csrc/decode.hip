@@ -578,8 +578,12 @@ extern "C" int capdec_beam_select(const void* logits, int ldl, const void* score
     // rows that can be staged in LDS (float4-readable, at most 60 KB: two or more workgroups per CU and no opt-in
     // for large dynamic LDS needed) take the one-read kernel.  Measured for V = 30 000 (tools/beam_select_time.py,
     // 2048 images x 5 beams): staging the 120 KB row (large-LDS opt-in, ONE workgroup per CU) takes 2.31 ms against
-    // 1.09 ms for the re-reading kernel -- the kernel is bound by its insertion network (vector issue), not by the
-    // logits reads, so the lost occupancy costs more than the two saved reads; such rows stay on the re-reading path
+    // 1.09 ms for the re-reading kernel, whose three passes run at 3.4 TB/s of logits reads: the lost occupancy costs more
+    // than the two saved reads.  Round 3 tried the two remaining ideas on that shape (measured, not kept): the row held
+    // in REGISTERS (120 per thread, read once, same element order: bit-identical) took 1.58 ms -- 266 registers, one
+    // wave per SIMD, spills --, and pruning the insertion network with a block-wide threshold (the (W+1)-th best
+    // candidate so far, raised after every row; nothing below it can win; bit-identical) changed nothing for the
+    // re-reading kernel (1.25 vs 1.10 ms): the insertions are not what it waits for.  Such rows stay on the re-reading path
     const size_t lds = (size_t)V * sizeof(float);
     const bool stage = V % 4 == 0 && ldl % 4 == 0 && aligned16(logits) && lds <= 60 * 1024;
 #define CAPDEC_BEAM(ST, LW) \

@@ -39,8 +39,33 @@ class GemmDesc(C.Structure):
                 ("ldb", _i), ("C", _vp), ("ldc", _i), ("ep", C.POINTER(Epilogue))]
 
 
+class TrainGeom(C.Structure):
+    """capdec_train_geom of include/capdec.h."""
+    _fields_ = [(n, _i) for n in ("B", "T", "S", "H", "d", "dff", "causal", "dtype")] + [("drop_p", _f)] + \
+               [(n, _i) for n in ("group_wgrads", "group_bm", "group_bn")]
+
+
+TRAIN_LAYER_PARAMS = ("w_in", "b_in", "w_out", "b_out", "ln1_w", "ln1_b", "wc_in", "bc_in", "wc_out", "bc_out", "ln2_w", "ln2_b",
+                      "w1", "b1", "w2", "b2", "ln3_w", "ln3_b")
+TRAIN_LAYER_COPIES = ("w_in16", "w_out16", "wcq16", "wc_out16", "w1_16", "w2_16")
+
+
+class TrainLayer(C.Structure):
+    """capdec_train_layer of include/capdec.h."""
+    _fields_ = [(n, _vp) for n in TRAIN_LAYER_PARAMS] + [("g_" + n, _vp) for n in TRAIN_LAYER_PARAMS] + \
+               [(n, _vp) for n in TRAIN_LAYER_COPIES] + [("ld_" + n, _i) for n in TRAIN_LAYER_COPIES] + \
+               [("arena", _vp), ("arena_bytes", _sz)]
+
+
+TL_X3, TL_X3_16, TL_DX, TL_SLOTS = 19, 20, 37, 41
+
 # name -> (restype, argtypes); mirrors include/capdec.h one to one
 SIGNATURES = {
+    "capdec_train_layer_arena_bytes": (_sz, [C.POINTER(TrainGeom)]),
+    "capdec_train_layer_slot": (_i, [C.POINTER(TrainGeom), _i, C.POINTER(_sz), C.POINTER(_sz), C.POINTER(_i), C.POINTER(_i)]),
+    "capdec_train_layer_fwd": (_i, [C.POINTER(TrainLayer), C.POINTER(TrainGeom), _i, _u64, _vp, _vp, _i, _vp, _i, _vp, _sz, _vp]),
+    "capdec_train_layer_bwd": (_i, [C.POINTER(TrainLayer), C.POINTER(TrainGeom), _i, _u64, _vp, _vp, _vp, _i, _vp, _vp, _i, _vp, _i,
+                                    _vp, _i, _vp, _sz, _vp, _sz, _vp, _vp]),
     "capdec_abi_version": (_i, []),
     "capdec_last_error": (C.c_char_p, []),
     "capdec_gemm_workspace_bytes": (_sz, [_i, _i, _i]),

@@ -158,6 +158,7 @@ def layer_bwd(P, G, sv, dx3, mem, dmem, B, T, S, H, causal, dp, l, dkv=None):
     du = ops.linear_dgrad(g3m, P["linear2.weight"], gelu_pre=sv["u"], drop_p=p, seed=dp.seed(sid + S_FFN_IN),
                           out=_like16(sv["h"], *sv["h"].shape))
     ops.linear_wgrad(du, sv["x2"], dw=G["linear1.weight"], db=G["linear1.bias"])
+    ops.wgrad_flush(stage=True)
     dx2 = ops.linear_dgrad(du, P["linear1.weight"], addend=g3)
     g2, g2m, _, _ = ops.layernorm_bwd(dx2, sv["s2"], P["norm2.weight"], P["norm2.bias"], sv["mean2"], sv["rstd2"],
                                       drop2_p=p, seed2=dp.seed(sid + S_CA_OUT), want_dx_drop=tr or d16c,
@@ -190,6 +191,7 @@ def layer_bwd(P, G, sv, dx3, mem, dmem, B, T, S, H, causal, dp, l, dkv=None):
             G["_cross_q_grads_zero"] = False
             ops.linear_wgrad(dq, sv["x1"], dw=gw[:d], db=gb[:d])
     ops.linear_wgrad(dkv, mem, dw=gw[d:], db=gb[d:])
+    ops.wgrad_flush(stage=True)
     if not batched:
         dmem = ops.linear_dgrad(dkv, wc[d:], addend=dmem)
     dx1 = g2 if S == 1 else ops.linear_dgrad(dq, wc[:d], addend=g2)
@@ -219,10 +221,11 @@ def kv_batched(n_layers, mem_rows):
     return n_layers > 1 and mem_rows >= 1024
 
 
-def stack_fwd(layers, norm_w, norm_b, x, mem, B, T, S, H, causal, dp, save, kv_stack=None):
+def stack_fwd(layers, norm_w, norm_b, x, mem, B, T, S, H, causal, dp, save, kv_stack=None, plans=None):
     """``kv_stack``: (w_all [L*2d, d], b_all [L*2d]), the layers' cross-attention K | V projection weights / biases
     already stacked (the trainer keeps such a block and refreshes it with one launch per step: ops.StackedRows);
-    None: concatenated here."""
+    None: concatenated here.  ``plans``: a train_plan.LayerPlans built over these layers for this geometry -- each
+    layer is then ONE C call per direction (same launches, same bits) instead of the op-by-op plan below."""
     saves = [] if save is not None else None
     # The cross-attention K/V projections of all layers depend only on the memory: one GEMM with the layers'
     # weights stacked ([L*2d, d], a 6 MB gather at C2) instead of L mid-size ones; each layer reads its
@@ -238,15 +241,21 @@ def stack_fwd(layers, norm_w, norm_b, x, mem, B, T, S, H, causal, dp, save, kv_s
         # bf16 storage: the block exists only as bf16 (capdec_epilogue.c16) and the all-bf16 attention kernels stream it
         kv_all = ops.linear_fwd(mem, w_all, b_all, out=ops.bf16_matrix(mem.shape[0], w_all.shape[0], x.device)
                                 if _attn16(H, d) and S > 1 else None)
-    for l, P in enumerate(layers):
-        sv = {} if save is not None else None
-        x = layer_fwd(P, x, mem, B, T, S, H, causal, dp, l, sv,
-                      kv=None if kv_all is None else kv_all[:, l * 2 * d:(l + 1) * 2 * d])
-        if saves is not None:
-            saves.append(sv)
+    if plans is not None and (kv_all is None or save is None):
+        raise ValueError("stack_fwd: one-call layer plans need the batched K | V projection and a training pass")
+    if plans is not None:
+        x = plans.forward(x, kv_all, dp.key)
+    else:
+        for l, P in enumerate(layers):
+            sv = {} if save is not None else None
+            x = layer_fwd(P, x, mem, B, T, S, H, causal, dp, l, sv,
+                          kv=None if kv_all is None else kv_all[:, l * 2 * d:(l + 1) * 2 * d])
+            if saves is not None:
+                saves.append(sv)
     y, mean, rstd = ops.layernorm_fwd(x, norm_w, norm_b, save_stats=save is not None)
     if save is not None:
-        save.update(layers=saves, xl=x, mean=mean, rstd=rstd, w_kv_all=w_all if kv_all is not None else None)
+        save.update(layers=saves, xl=x, mean=mean, rstd=rstd, w_kv_all=w_all if kv_all is not None else None,
+                    plans=plans, kv_all=kv_all if plans is not None else None)
     return y
 
 
@@ -274,11 +283,17 @@ def stack_bwd(layers, grads, norm_w, norm_b, g_norm_w, g_norm_b, sv, dy, mem, B,
                 dkv_all = ops._zero_padded(dkv_all)
         else:
             dkv_all = torch.empty((mem.shape[0], w_all.shape[0]), dtype=torch.float32, device=dy.device)
-    for l in range(len(layers) - 1, -1, -1):
-        dx, dmem = layer_bwd(layers[l], grads[l], sv["layers"][l], dx, mem, dmem, B, T, S, H, causal, dp, l,
-                             dkv=None if dkv_all is None else dkv_all[:, l * 2 * d:(l + 1) * 2 * d])
-        if after_layer is not None:
-            after_layer(l)
+    if sv.get("plans") is not None:
+        for G in grads:  # (the plans cover S > 1 only: the query rows of the cross-attention in-projection get real gradients)
+            if "_cross_q_grads_zero" in G:
+                G["_cross_q_grads_zero"] = False
+        dx = sv["plans"].backward(dx, mem, sv["kv_all"], dkv_all, dp.key, after_layer)
+    else:
+        for l in range(len(layers) - 1, -1, -1):
+            dx, dmem = layer_bwd(layers[l], grads[l], sv["layers"][l], dx, mem, dmem, B, T, S, H, causal, dp, l,
+                                 dkv=None if dkv_all is None else dkv_all[:, l * 2 * d:(l + 1) * 2 * d])
+            if after_layer is not None:
+                after_layer(l)
     if dkv_all is not None:
         dmem = ops.linear_dgrad(dkv_all, w_all)
     return dx, dmem
@@ -330,6 +345,7 @@ def head_bwd(P, G, sv, dlogits, dp, ce=None):
     """``ce = (lse, targets, eps, grad_scale)``: ``dlogits`` is still the LOGITS block; both products read it through
     the cross-entropy gradient transform in their loaders (nothing is written back to the block)."""
     ops.linear_wgrad(dlogits, sv["h"], dw=G["3.weight"], db=G["3.bias"], ce=ce)
+    ops.wgrad_flush()  # the big one: on the lane before the input-gradient product is enqueued, so that they overlap
     du = ops.linear_dgrad(dlogits, P["3.weight"], gelu_pre=sv["u"], drop_p=dp.p, seed=dp.seed(S_HEAD), ce=ce,
                           out=_like16(sv["h"], *sv["h"].shape))
     ops.linear_wgrad(du, sv["x"], dw=G["0.weight"], db=G["0.bias"])

@@ -528,9 +528,10 @@ def linear_dgrad(dy, w, out=None, addend=None, gelu_pre=None, drop_p=0.0, seed=0
 
 # ---- grouped weight gradients --------------------------------------------------------------------------------------
 # The weight gradients of a decoder layer are small products (64 - 256 output tiles each) that are all ready by the end
-# of the layer's backward and that nothing needs before the optimizer: with GROUP_WGRADS on, linear_wgrad only queues
-# them (exact fp32, side lane active, caller-owned outputs) and wgrad_flush() -- called by the engine at the end of a
-# block's backward -- launches up to GEMM_GROUP_MAX of them as ONE chip-filling, unsplit grid (capdec_gemm_grouped).
+# of the layer's backward and that nothing needs before the optimizer: with a side lane active, linear_wgrad only queues
+# them (caller-owned outputs) and wgrad_flush() -- called by the engine at the end of a block's backward -- hands them to
+# the lane in ONE hand-over; with GROUP_WGRADS on, the exact-fp32 ones go out as launches of up to GEMM_GROUP_MAX
+# products each (capdec_gemm_grouped: one chip-filling, unsplit grid).
 GROUP_WGRADS = os.environ.get("CAPDEC_GROUP_WGRADS", "1") == "1"
 GROUP_TILE = (0, 0)   # block tile of the grouped launches ((0, 0) = the library's default, 64 x 64)
 _WGRAD_QUEUE = []
@@ -565,26 +566,46 @@ def _groupable(t):
     return t.dtype == torch.float32 and t.dim() == 2 and t.stride(1) == 1 and t.stride(0) % 4 == 0 and t.data_ptr() % 16 == 0
 
 
-def wgrad_flush():
-    """Launch the queued weight gradients (grouped by GEMM_GROUP_MAX) on the side lane."""
-    global _WGRAD_QUEUE
+def wgrad_flush(stage=False):
+    """Hand the queued weight gradients to the side lane: ONE hand-over (event record + wait, stream switch) for all
+    of them; the exact-fp32 ones without cross-entropy fusion go out as grouped launches, the rest one by one.
+    ``stage=True`` marks a point INSIDE a block (end of its FFN / cross-attention part): the queue is handed over
+    there only when its products would go out one by one anyway, so that the lane starts them while the block's
+    backward is still running; products that wait for a grouped launch stay queued until the block's end."""
+    global _WGRAD_QUEUE, COMPUTE_DTYPE
     if not _WGRAD_QUEUE:
         return
-    q, _WGRAD_QUEUE = _WGRAD_QUEUE, []
-    if SIDE is None:  # (the lane went away between queueing and flushing: run them here)
-        for dy, x, dw, db in q:
-            gemm(dy, x, True, False, out=dw, colsum=db)
+    if stage and GROUP_WGRADS and TUNE_RECORD is None and all(e[5] == F32 and e[4] is None for e in _WGRAD_QUEUE):
         return
+    q, _WGRAD_QUEUE = _WGRAD_QUEUE, []
+    group = [e for e in q if e[5] == F32 and e[4] is None and GROUP_WGRADS and TUNE_RECORD is None and _groupable(e[0])
+             and _groupable(e[1]) and _groupable(e[2])]
+    if len(group) < 2:
+        group = []
+    single = [e for e in q if not any(e is g for g in group)]
     # longest reductions first: their tiles start first and the short ones fill the tail of the launch
-    q.sort(key=lambda e: -e[0].shape[0])
-    for i in range(0, len(q), _capi.GEMM_GROUP_MAX):
-        part = q[i:i + _capi.GEMM_GROUP_MAX]
-        if len(part) == 1:
-            dy, x, dw, db = part[0]
-            SIDE.run(lambda: gemm(dy, x, True, False, out=dw, colsum=db), dy, x)
-        else:
-            SIDE.run(lambda: gemm_grouped([(dy, x, True, False, dw, db) for dy, x, dw, db in part], GROUP_TILE),
-                     *[t for e in part for t in e[:2]])
+    group.sort(key=lambda e: -e[0].shape[0])
+
+    def issue():
+        global COMPUTE_DTYPE
+        for i in range(0, len(group), _capi.GEMM_GROUP_MAX):
+            part = group[i:i + _capi.GEMM_GROUP_MAX]
+            if len(part) == 1:
+                single.append(part[0])
+            else:
+                gemm_grouped([(dy, x, True, False, dw, db) for dy, x, dw, db, _, _ in part], GROUP_TILE)
+        saved = COMPUTE_DTYPE
+        try:
+            for dy, x, dw, db, ce, dtype in single:
+                COMPUTE_DTYPE = dtype
+                gemm(dy, x, True, False, out=dw, colsum=db, ce=ce)
+        finally:
+            COMPUTE_DTYPE = saved
+
+    if SIDE is None:  # (the lane went away between queueing and flushing: run them here)
+        issue()
+    else:
+        SIDE.run(issue, *[t for e in q for t in e[:2]])
 
 
 def linear_wgrad(dy, x, dw=None, db=None, ce=None):
@@ -592,14 +613,12 @@ def linear_wgrad(dy, x, dw=None, db=None, ce=None):
 
     With a SideStream active and caller-owned outputs, the product is enqueued on the side stream
     (ordered after everything enqueued so far on the current stream) and the call returns at once."""
-    if SIDE is not None and dw is not None and GROUP_WGRADS and COMPUTE_DTYPE == F32 and ce is None and TUNE_RECORD is None \
-            and _groupable(dy) and _groupable(x) and _groupable(dw):
-        _WGRAD_QUEUE.append((dy, x, dw, db))
-        return dw
     if SIDE is not None and dw is not None:
+        # queued: wgrad_flush() (the engine calls it at the end of a block's backward) hands the block's weight
+        # gradients to the lane together -- one hand-over instead of one per product
         if COMPUTE_DTYPE == _capi.BF16S:  # bf16 copies are made (or found) on the caller's stream, not on the lane
             dy, x = _bf16_operand(dy, "linear_wgrad.dy"), _bf16_operand(x, "linear_wgrad.x")
-        SIDE.run(lambda: gemm(dy, x, True, False, out=dw, colsum=db, ce=ce), dy, x)
+        _WGRAD_QUEUE.append((dy, x, dw, db, ce, COMPUTE_DTYPE))
         return dw
     return gemm(dy, x, True, False, out=dw, colsum=db, ce=ce)
 

@@ -22,7 +22,9 @@ but as a fixed launch plan over flat HBM-resident blocks instead of autograd ove
 import torch
 import torch.distributed as dist
 
-from . import engine, ops
+import os
+
+from . import _capi, engine, ops, train_plan
 from .engine import DropoutPlan
 from .parallel import BucketReducer, EqualRowsGuard, FlatParams, decoder_param_groups
 
@@ -97,6 +99,10 @@ class CaptionTrainer:
         # off (then each weight is cast by the first product of the step that reads it: same values, ~40 launches)
         self._w16, self.one_launch_weight_casts = None, True
         self.side = ops.SideStream(dev) if (side_stream_wgrad and dev.type == "cuda") else None
+        # each decoder layer as ONE C call per direction (train_plan.LayerPlans) wherever those plans cover the step;
+        # False: the op-by-op launch plan of engine.layer_fwd / layer_bwd (same launches, same bits, more host time)
+        self.one_call_layers = os.environ.get("CAPDEC_ONE_CALL_LAYERS", "1") == "1"
+        self._plans = None
         # data-parallel ranks must all run the same B*T (the loss gradient is pre-scaled by 1/(rows*world)): checked by
         # a collective that every rank issues on every step (parallel.EqualRowsGuard)
         self._rows_guard = EqualRowsGuard(process_group, dev)
@@ -127,6 +133,7 @@ class CaptionTrainer:
         for G in self.G_layers:  # these views are written by this trainer's launches only (engine._zero_query_grads)
             G["_cross_q_grads_zero"] = False
         self._kv_stack = None
+        self._plans = None
         fp = m.feature_projection
         self.P_proj = dict(zip(engine.PROJ_KEYS, [fp[0].weight, fp[0].bias, fp[1].weight, fp[1].bias, fp[4].weight,
                                                   fp[4].bias, fp[5].weight, fp[5].bias]))
@@ -134,6 +141,33 @@ class CaptionTrainer:
         ol = m.output_layer
         self.P_head = dict(zip(engine.HEAD_KEYS, [ol[0].weight, ol[0].bias, ol[3].weight, ol[3].bias]))
         self.G_head = {k: v.grad for k, v in self.P_head.items()}
+
+    def _layer_plans(self, B, T, S, mem, drop_p):
+        """The one-call layer plans for this step's geometry, or None where they do not apply (then engine.layer_fwd /
+        layer_bwd run op by op): switched off, a recording / per-launch-timing pass, a geometry they do not cover, or
+        bf16 storage before the persistent weight copies exist (the first step of a run)."""
+        if not self.one_call_layers or ops.TUNE_RECORD is not None or ops.PROFILE is not None or mem.device.type != "cuda":
+            return None
+        dtype = ops.COMPUTE_DTYPE
+        P0 = self.P_layers[0]
+        dff, d = P0["linear1.weight"].shape
+        if not train_plan.covers(B, T, S, self.nhead, d, dff, dtype, self.nl, mem.shape[0]):
+            return None
+        copies = None
+        if dtype == _capi.BF16S:
+            if self._w16 is None or not self.one_launch_weight_casts:
+                return None
+            copies = self._w16.memo()
+        key = (B, T, S, self.nhead, True, float(drop_p), dtype, bool(ops.GROUP_WGRADS and ops.SIDE is not None),
+               tuple(ops.GROUP_TILE))
+        if self._plans is None or self._plans.key != key:
+            self._plans = None  # (the old arenas go back to the allocator before the new ones are asked for)
+            try:
+                self._plans = train_plan.LayerPlans(self.P_layers, self.G_layers, B, T, S, self.nhead, True, drop_p, dtype,
+                                                    mem.device, copies)
+            except KeyError:  # a weight operand without a persistent bf16 copy: stay with the op-by-op plan
+                return None
+        return self._plans
 
     # ---- one iteration of ref train.py:24-61 ---------------------------------------------------------
     def forward_backward(self, features, captions, train=True, keep_logits=False):
@@ -200,7 +234,7 @@ class CaptionTrainer:
                                   ops.StackedRows([P["multihead_attn.in_proj_bias"][d:] for P in self.P_layers]))
             kv_stack = (self._kv_stack[0].refresh(), self._kv_stack[1].refresh())
         y = engine.stack_fwd(self.P_layers, dec.norm.weight, dec.norm.bias, x.view(B * T, -1), mem, B, T, S, self.nhead,
-                             True, dp, sv_stack, kv_stack=kv_stack)
+                             True, dp, sv_stack, kv_stack=kv_stack, plans=self._layer_plans(B, T, S, mem, dp.p))
         # the logits block (B*T x V fp32, the step's largest tensor) is owned by the trainer: one allocation
         # for the run instead of a 100+ MB request to the caching allocator every step
         if self._logits is None or tuple(self._logits.shape) != (B * T, self.P_head["3.weight"].shape[0]):

@@ -445,6 +445,59 @@ size_t capdec_decode_step_workspace_bytes(int R, int d, int dff);
 int capdec_decode_step(const capdec_decode_layer* layers, int L, void* x, const int* anc, int R, int H, int d, int dff,
                        int Tmax, int t, int W, int S, int dtype, void* workspace, size_t workspace_bytes,
                        void* gemm_workspace, size_t gemm_workspace_bytes, capdec_stream_t stream);
+/* ---- one decoder layer of a TRAINING step per call ------------------------------------------------------------------
+ * capdec_train_layer_fwd / _bwd enqueue, from ONE call each, every launch of a post-norm decoder layer
+ * (torch/nn/modules/transformer.py:1143-1199 as built at ref models.py:53-65, teacher-forced as ref train.py:24-61 runs
+ * it) and of its autograd backward: packed in-projection, causal self-attention, out-projection + dropout + residual,
+ * LayerNorm, cross-attention over the image memory (S > 1 positions), LayerNorm, FFN (GELU), LayerNorm; backward in
+ * reverse, with the layer's seven weight gradients and three LayerNorm parameter gradients handed to `lane_stream`
+ * (ordered after their producers by events; the critical path never waits for them -- the CALLER joins the lane before
+ * it reads the gradients).  Exactly the entry points above, with the arguments and in the per-stream order a caller
+ * issuing them one by one would use (imagecaption_amd/engine.py layer_fwd / layer_bwd): bit-identical results.  What it
+ * removes is the caller's per-launch host cost, which bounds the bf16-storage step.
+ *   geometry: B images x T tokens, memory of S > 1 positions, H heads, model width d, FFN width dff; `dtype` is the
+ *     compute type of every product (CAPDEC_BF16S: d, dff multiples of 64, head dim 64 or 128 -- the all-bf16
+ *     attention kernels); drop_p the dropout probability of all six sites, whose seeds are
+ *     splitmix64(dropout_key ^ (16 * layer + site) * 0xD6E8FEB86659FD93) (engine.DropoutPlan); group_wgrads: with
+ *     CAPDEC_F32, the weight gradients go out as one capdec_gemm_grouped launch of tile group_bm x group_bn.
+ *   layer: fp32 parameters and their gradients (dense, the reference's state_dict shapes; gradients are OVERWRITTEN),
+ *     with CAPDEC_BF16S also zero-padded bf16 copies of the six weight matrices (wcq16: rows 0..d-1 of
+ *     multihead_attn.in_proj_weight, the query block), refreshed by the caller before the step; `arena`:
+ *     capdec_train_layer_arena_bytes(geom) bytes, 256-byte aligned, owned by this layer from its forward to the end of
+ *     its backward's lane work.  capdec_train_layer_slot gives offset / size / row stride / element type of a tensor
+ *     inside it (slot ids: CAPDEC_TL_*): the layer output x3 (+ its bf16 copy), the input gradient dx.
+ *   fwd: x [B*T, d] fp32 (+ x16, its bf16 copy, with CAPDEC_BF16S); kv [B*S, 2d] = this layer's K | V projection of
+ *     the memory (row stride ldkv; bf16 with CAPDEC_BF16S) from the caller's batched product.
+ *   bwd: dy [B*T, d] fp32, the x / x16 / kv of the forward call, mem [B*S, d] (+ mem16), dkv [B*S, 2d] receiving
+ *     dK | dV (fp32, or bf16 with CAPDEC_BF16S; the caller's batched d(memory) product reads it).  Each stream needs a
+ *     capdec_gemm workspace of its own.  lane_stream == stream runs everything on one stream. */
+typedef struct capdec_train_geom {
+    int B, T, S, H, d, dff, causal, dtype;
+    float drop_p;
+    int group_wgrads, group_bm, group_bn;
+} capdec_train_geom;
+typedef struct capdec_train_layer {
+    const void *w_in, *b_in, *w_out, *b_out, *ln1_w, *ln1_b, *wc_in, *bc_in, *wc_out, *bc_out, *ln2_w, *ln2_b, *w1, *b1, *w2,
+        *b2, *ln3_w, *ln3_b;
+    void *g_w_in, *g_b_in, *g_w_out, *g_b_out, *g_ln1_w, *g_ln1_b, *g_wc_in, *g_bc_in, *g_wc_out, *g_bc_out, *g_ln2_w,
+        *g_ln2_b, *g_w1, *g_b1, *g_w2, *g_b2, *g_ln3_w, *g_ln3_b;
+    const void *w_in16, *w_out16, *wcq16, *wc_out16, *w1_16, *w2_16; /* CAPDEC_BF16S only */
+    int ld_w_in16, ld_w_out16, ld_wcq16, ld_wc_out16, ld_w1_16, ld_w2_16;
+    void* arena;
+    size_t arena_bytes;
+} capdec_train_layer;
+enum { CAPDEC_TL_X3 = 19, CAPDEC_TL_X3_16 = 20, CAPDEC_TL_DX = 37, CAPDEC_TL_SLOTS = 41 };
+size_t capdec_train_layer_arena_bytes(const capdec_train_geom* geom);
+int capdec_train_layer_slot(const capdec_train_geom* geom, int slot, size_t* offset, size_t* bytes, int* ld, int* is_bf16);
+int capdec_train_layer_fwd(const capdec_train_layer* layer, const capdec_train_geom* geom, int layer_index,
+                           uint64_t dropout_key, const void* x, const void* x16, int ldx16, const void* kv, int ldkv,
+                           void* gemm_workspace, size_t gemm_workspace_bytes, capdec_stream_t stream);
+int capdec_train_layer_bwd(const capdec_train_layer* layer, const capdec_train_geom* geom, int layer_index,
+                           uint64_t dropout_key, const void* dy, const void* x, const void* x16, int ldx16, const void* mem,
+                           const void* mem16, int ldmem16, const void* kv, int ldkv, void* dkv, int lddkv,
+                           void* gemm_workspace, size_t gemm_workspace_bytes, void* lane_gemm_workspace,
+                           size_t lane_gemm_workspace_bytes, capdec_stream_t stream, capdec_stream_t lane_stream);
+
 int capdec_greedy_select(const void* logits, int ldl, int* done, int* seq, int64_t* next_tok, void* gap, int R, int V,
                          int Tmax, int t, capdec_stream_t stream);
 int capdec_beam_select(const void* logits, int ldl, const void* score_in, void* score_out, const int* fin_in,

@@ -24,4 +24,15 @@ for side in (True, False):
     t1 = time.perf_counter()
     torch.cuda.synchronize()
     t2 = time.perf_counter()
-    print(f"{dtype} side={side}: host enqueue {(t1-t0)/20*1e3:.2f} ms/step, total {(t2-t0)/20*1e3:.2f} ms/step", flush=True)
+    # 20 steps in a row run the host ~1500 dispatches ahead of the GPU, where the launch path starts to block: the pure
+    # host cost is what a SHORT burst takes (4 steps from an idle queue, best of 5)
+    burst = []
+    for _ in range(5):
+        torch.cuda.synchronize()
+        b0 = time.perf_counter()
+        for _ in range(4):
+            tr.step(f, c)
+        burst.append((time.perf_counter() - b0) / 4)
+    torch.cuda.synchronize()
+    print(f"{dtype} side={side} one_call_layers={tr._plans is not None}: host enqueue {(t1-t0)/20*1e3:.2f} ms/step over 20 steps, "
+          f"{min(burst)*1e3:.2f} ms/step in a 4-step burst; total {(t2-t0)/20*1e3:.2f} ms/step", flush=True)

@@ -27,6 +27,8 @@
 // K rounded up to 64, zero-filled by capdec_cast_bf16) -- the host side picks this kernel only when that holds
 // (launch_gemm_bf16s).
 #include "common.h"
+#include <type_traits>
+
 #include "gemm_common.h"
 
 namespace capdec {
@@ -85,6 +87,23 @@ struct DmaSrc {
 // SPLITK: the kernel contains the in-launch split-K combine.  Its code (cold, but part of the same register
 // allocation) costs ~20 VGPRs -- the difference between three and four resident workgroups per CU for the one-image
 // 128 x 128 form -- so unsplit launches get an instantiation without it.
+// The transposing read as inline assembly: the BUILTIN gets a compiler-inserted s_waitcnt vmcnt(0) whenever an LDS DMA is
+// in flight (see attention_bf16.hip), which in the two-image form below stood between the request for k-tile kt + 1 and
+// the first fragment read of k-tile kt -- the prefetch of every product with a k-major operand was fully serialised
+// (found in round 3 by reading the ISA).  The callers wait with their own lgkmcnt tied to the results.
+__device__ __forceinline__ s16x4 pair_read_tr16(unsigned addr) {  // inline assembly: see attention_bf16.hip
+    s16x4 v;
+    asm volatile("ds_read_b64_tr_b16 %0, %1" : "=v"(v) : "v"(addr));
+    return v;
+}
+
+template <int OFF>
+__device__ __forceinline__ s16x4 pair_read_tr16_at(unsigned addr) {  // the same with an immediate byte offset
+    s16x4 v;
+    asm volatile("ds_read_b64_tr_b16 %0, %1 offset:%2" : "=v"(v) : "v"(addr), "n"(OFF));
+    return v;
+}
+
 template <bool AKC, bool BKC, int NBUF, bool SPLITK>
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(NBUF == 1 ? (SPLITK ? 3 : 4) : 2)))
 void gemm_bf16s_dma_kernel(GemmParams p) {
@@ -126,6 +145,7 @@ void gemm_bf16s_dma_kernel(GemmParams p) {
     sb.init(p.ldb, n0, p.N, wave, lane);
     unsigned char* img_a = smem + wave * 4096;          // this wave's DMA destinations (wave-uniform)
     unsigned char* img_b = smem + D_IMG + wave * 4096;
+    const unsigned lds0 = (unsigned)(size_t)(const __attribute__((address_space(3))) unsigned char*)smem;
 
     // fragment read offsets (bytes inside an image)
     //   k-contiguous: row * 128 + (((ks * 2) ^ c) * 16), c = half ^ ((l31 >> 1) & 7)
@@ -208,18 +228,47 @@ void gemm_bf16s_dma_kernel(GemmParams p) {
         }
         const unsigned char* As = smem + buf * 2 * D_IMG;
         const unsigned char* Bs = As + D_IMG;
+        const unsigned as0 = lds0 + buf * 2 * D_IMG, bs0 = as0 + D_IMG;
+        // k-major operands: transposing reads in inline assembly, one 16-deep k-step ahead of the products that use them
+        s16x4 ta[2][TM][2], tb[2][TN][2];
+        auto issue_tr = [&](auto ks_c, int pb) {
+            constexpr int KS = decltype(ks_c)::value;
+            if constexpr (!AKC) {
 #pragma unroll
-        for (int ks = 0; ks < DBK / 16; ++ks) {
+                for (int i = 0; i < TM; ++i) {
+                    ta[pb][i][0] = pair_read_tr16_at<KS * 4096>(as0 + offa[i][0]);
+                    ta[pb][i][1] = pair_read_tr16_at<KS * 4096>(as0 + offa[i][1]);
+                }
+            }
+            if constexpr (!BKC) {
+#pragma unroll
+                for (int j = 0; j < TN; ++j) {
+                    tb[pb][j][0] = pair_read_tr16_at<KS * 4096>(bs0 + offb[j][0]);
+                    tb[pb][j][1] = pair_read_tr16_at<KS * 4096>(bs0 + offb[j][1]);
+                }
+            }
+        };
+        auto retire_tr = [&](int pb) {  // every LDS read issued so far has returned
+            static_assert(TM == 2 && TN == 2, "the operand lists below name 2 x 2 fragments");
+            if constexpr (!AKC)
+                asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(ta[pb][0][0]), "+v"(ta[pb][0][1]), "+v"(ta[pb][1][0]), "+v"(ta[pb][1][1]));
+            if constexpr (!BKC)
+                asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(tb[pb][0][0]), "+v"(tb[pb][0][1]), "+v"(tb[pb][1][0]), "+v"(tb[pb][1][1]));
+        };
+        auto k_step = [&](auto ks_c) {
+            constexpr int ks = decltype(ks_c)::value;
             bf16x8d af[TM], bfr[TN];
+            constexpr int pb = ks & 1;
+            if constexpr (!AKC || !BKC) {
+                retire_tr(pb);
+                if constexpr (ks + 1 < DBK / 16) issue_tr(std::integral_constant<int, ks + 1>{}, pb ^ 1);
+            }
 #pragma unroll
             for (int i = 0; i < TM; ++i) {
                 if constexpr (AKC) {
                     af[i] = *reinterpret_cast<const bf16x8d*>(As + offa[i][0] + (offa[i][1] ^ (ks * 32)));
                 } else {
-                    const s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16(
-                        (s16x4 __attribute__((address_space(3)))*)(As + offa[i][0] + ks * 4096));
-                    const s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16(
-                        (s16x4 __attribute__((address_space(3)))*)(As + offa[i][1] + ks * 4096));
+                    const s16x4 lo = ta[pb][i][0], hi = ta[pb][i][1];
                     const s16x8 v = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
                     af[i] = __builtin_bit_cast(bf16x8d, v);
                 }
@@ -229,10 +278,7 @@ void gemm_bf16s_dma_kernel(GemmParams p) {
                 if constexpr (BKC) {
                     bfr[j] = *reinterpret_cast<const bf16x8d*>(Bs + offb[j][0] + (offb[j][1] ^ (ks * 32)));
                 } else {
-                    const s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16(
-                        (s16x4 __attribute__((address_space(3)))*)(Bs + offb[j][0] + ks * 4096));
-                    const s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16(
-                        (s16x4 __attribute__((address_space(3)))*)(Bs + offb[j][1] + ks * 4096));
+                    const s16x4 lo = tb[pb][j][0], hi = tb[pb][j][1];
                     const s16x8 v = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
                     bfr[j] = __builtin_bit_cast(bf16x8d, v);
                 }
@@ -242,7 +288,13 @@ void gemm_bf16s_dma_kernel(GemmParams p) {
 #pragma unroll
                 for (int j = 0; j < TN; ++j)
                     acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[i], bfr[j], acc[i][j], 0, 0, 0);
-        }
+        };
+        static_assert(DBK == 64, "four 16-deep k-steps per k-tile");
+        if constexpr (!AKC || !BKC) issue_tr(std::integral_constant<int, 0>{}, 0);
+        k_step(std::integral_constant<int, 0>{});
+        k_step(std::integral_constant<int, 1>{});
+        k_step(std::integral_constant<int, 2>{});
+        k_step(std::integral_constant<int, 3>{});
         if (do_colsum) {
             if constexpr (AKC) {  // row sums of the A image (pieces in swizzled order: a sum does not care)
                 if (tid < BM) {
@@ -310,12 +362,6 @@ void gemm_bf16s_dma_kernel(GemmParams p) {
 // A 32-deep stage ring (three stages in flight, 64-byte image rows) was tried first: 500 TFLOP/s on the products with
 // two k-contiguous operands whatever its depth -- DMA pieces of 16 rows x 64 B cost the address path twice what
 // 8 rows x 128 B do -- and on par with the 128 x 128 form where an operand is k-major.
-__device__ __forceinline__ s16x4 pair_read_tr16(unsigned addr) {  // inline assembly: see attention_bf16.hip
-    s16x4 v;
-    asm volatile("ds_read_b64_tr_b16 %0, %1" : "=v"(v) : "v"(addr));
-    return v;
-}
-
 template <bool AKC, bool BKC, bool SPLITK>
 __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2)))
 void gemm_bf16s_pair_kernel(GemmParams p) {

@@ -42,7 +42,7 @@ class GemmDesc(C.Structure):
 class TrainGeom(C.Structure):
     """capdec_train_geom of include/capdec.h."""
     _fields_ = [(n, _i) for n in ("B", "T", "S", "H", "d", "dff", "causal", "dtype")] + [("drop_p", _f)] + \
-               [(n, _i) for n in ("group_wgrads", "group_bm", "group_bn")]
+               [(n, _i) for n in ("group_wgrads", "group_bm", "group_bn", "wgrad_flush_mask")]
 
 
 TRAIN_LAYER_PARAMS = ("w_in", "b_in", "w_out", "b_out", "ln1_w", "ln1_b", "wc_in", "bc_in", "wc_out", "bc_out", "ln2_w", "ln2_b",

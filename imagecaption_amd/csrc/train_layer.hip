@@ -341,9 +341,6 @@ extern "C" int capdec_train_layer_bwd(const capdec_train_layer* P, const capdec_
     };
     WG queue[8];
     int nq = 0;
-    auto wgrad = [&](Mat dyv, Mat xv, int N, int K, int rows, void* dw, void* db) {
-        queue[nq++] = WG{dyv, xv, N, K, rows, dw, K, db};
-    };
     // (LayerNorm parameter gradients ride on the next hand-over: a hand-over costs ~25 us of host time on this stack)
     struct LNFin {
         const void* part;
@@ -353,8 +350,8 @@ extern "C" int capdec_train_layer_bwd(const capdec_train_layer* P, const capdec_
     int nfin = 0;
     auto flush = [&](bool stage) -> int {
         if (nq == 0 && nfin == 0) return CAPDEC_OK;
-        const bool grouping = g->dtype == CAPDEC_F32 && g->group_wgrads;
-        if (stage && grouping) return CAPDEC_OK;  // (they wait for the grouped launch at the end of the layer)
+        const bool grouping = g->dtype == CAPDEC_F32 && g->group_wgrads != 0;
+        if (stage && grouping) return CAPDEC_OK;  // (they wait for the grouped launch at the layer's end)
         STEP(hand_over(st, lane));
         for (int i = 0; i < nfin; ++i) STEP(capdec_layernorm_bwd_dparams(fin[i].part, fin[i].dgamma, fin[i].dbeta, M, d, lane_stream));
         nfin = 0;
@@ -400,6 +397,15 @@ extern "C" int capdec_train_layer_bwd(const capdec_train_layer* P, const capdec_
         nq = 0;
         return CAPDEC_OK;
     };
+    // hand-over points inside the layer (measured at C2: two of them beat both "each product at once" and "all at the
+    // layer's end" by 1 - 2 % of the step -- where the lane's products start decides which critical-path kernels they share
+    // the matrix pipes with)
+    const int flush_mask = g->wgrad_flush_mask ? g->wgrad_flush_mask : 0x12;
+    int nwg = 0;
+    auto wgrad = [&](Mat dyv, Mat xv, int N, int K, int rows, void* dw, void* db) -> int {
+        queue[nq++] = WG{dyv, xv, N, K, rows, dw, K, db};
+        return (flush_mask >> nwg++) & 1 ? flush(true) : CAPDEC_OK;
+    };
     // LayerNorm backward: dx (+ the dropout-masked copy the branch products read) on the critical path, the parameter
     // gradients (weight gradients: nothing later in backward reads them) from private partials on the lane
     auto ln_bwd = [&](const void* dyv, int s_x, const void* gamma, const void* beta, int s_mean, int s_rstd, int s_dx, int s_dxm,
@@ -419,12 +425,11 @@ extern "C" int capdec_train_layer_bwd(const capdec_train_layer* P, const capdec_
     // ---- feed-forward block
     STEP(ln_bwd(dy, SL_S3, P->ln3_w, P->ln3_b, SL_MEAN3, SL_RSTD3, SL_G3, SL_G3M, seed(S_FFN_OUT), SL_PART3, P->g_ln3_w, P->g_ln3_b));
     const Mat g3m = masked(SL_G3, SL_G3M);
-    wgrad(g3m, Mat{at(SL_H), ld(SL_H)}, d, dff, M, P->g_w2, P->g_b2);
+    STEP(wgrad(g3m, Mat{at(SL_H), ld(SL_H)}, d, dff, M, P->g_w2, P->g_b2));
     capdec_epilogue ep = ep0();
     ep.aux = at(SL_U); ep.act = CAPDEC_ACT_GELU_BWD; ep.drop_p = p; ep.drop_seed = seed(S_FFN_IN);
     STEP(G.run(0, 0, M, dff, d, g3m, W(P->w2, P->w2_16, P->ld_w2_16, dff), at(SL_DU), ld(SL_DU), s16, ep));
-    wgrad(Mat{at(SL_DU), ld(SL_DU)}, act16(SL_X2, SL_X2_16), dff, d, M, P->g_w1, P->g_b1);
-    STEP(flush(true));
+    STEP(wgrad(Mat{at(SL_DU), ld(SL_DU)}, act16(SL_X2, SL_X2_16), dff, d, M, P->g_w1, P->g_b1));
     ep = ep0();
     ep.addend = at(SL_G3); ep.ld_addend = d;
     STEP(G.run(0, 0, M, d, dff, Mat{at(SL_DU), ld(SL_DU)}, W(P->w1, P->w1_16, P->ld_w1_16, d), at(SL_DX2), d, false, ep));
@@ -432,15 +437,14 @@ extern "C" int capdec_train_layer_bwd(const capdec_train_layer* P, const capdec_
     STEP(ln_bwd(at(SL_DX2), SL_S2, P->ln2_w, P->ln2_b, SL_MEAN2, SL_RSTD2, SL_G2, SL_G2M, seed(S_CA_OUT), SL_PART2, P->g_ln2_w,
                 P->g_ln2_b));
     const Mat g2m = masked(SL_G2, SL_G2M);
-    wgrad(g2m, Mat{at(SL_C), ld(SL_C)}, d, d, M, P->g_wc_out, P->g_bc_out);
+    STEP(wgrad(g2m, Mat{at(SL_C), ld(SL_C)}, d, d, M, P->g_wc_out, P->g_bc_out));
     STEP(G.run(0, 0, M, d, d, g2m, W(P->wc_out, P->wc_out16, P->ld_wc_out16, d), at(SL_DC), ld(SL_DC), s16, ep0()));
     STEP(attn_bwd(at(SL_Q), ld(SL_Q), kv, ldkv, col(kv, s16, d), ldkv, at(SL_C), ld(SL_C), at(SL_DC), ld(SL_DC), at(SL_LSE2),
                   at(SL_DELTA), at(SL_DQ), ld(SL_DQ), dkv, lddkv, col(dkv, s16, d), lddkv, B, H, T, S, dh, 0, scale, p, seed(S_CA_P),
                   stream));
-    wgrad(Mat{at(SL_DQ), ld(SL_DQ)}, act16(SL_X1, SL_X1_16), d, d, M, P->g_wc_in, P->g_bc_in);
-    wgrad(Mat{dkv, lddkv}, s16 ? Mat{mem16, ldmem16} : Mat{mem, d}, 2 * d, d, Ms, (float*)P->g_wc_in + (size_t)d * d,
-          (float*)P->g_bc_in + d);
-    STEP(flush(true));
+    STEP(wgrad(Mat{at(SL_DQ), ld(SL_DQ)}, act16(SL_X1, SL_X1_16), d, d, M, P->g_wc_in, P->g_bc_in));
+    STEP(wgrad(Mat{dkv, lddkv}, s16 ? Mat{mem16, ldmem16} : Mat{mem, d}, 2 * d, d, Ms, (float*)P->g_wc_in + (size_t)d * d,
+               (float*)P->g_bc_in + d));
     ep = ep0();
     ep.addend = at(SL_G2); ep.ld_addend = d;
     STEP(G.run(0, 0, M, d, d, Mat{at(SL_DQ), ld(SL_DQ)}, W(P->wc_in, P->wcq16, P->ld_wcq16, d), at(SL_DX1), d, false, ep));
@@ -448,14 +452,14 @@ extern "C" int capdec_train_layer_bwd(const capdec_train_layer* P, const capdec_
     STEP(ln_bwd(at(SL_DX1), SL_S1, P->ln1_w, P->ln1_b, SL_MEAN1, SL_RSTD1, SL_G1, SL_G1M, seed(S_SA_OUT), SL_PART1, P->g_ln1_w,
                 P->g_ln1_b));
     const Mat g1m = masked(SL_G1, SL_G1M);
-    wgrad(g1m, Mat{at(SL_A), ld(SL_A)}, d, d, M, P->g_w_out, P->g_b_out);
+    STEP(wgrad(g1m, Mat{at(SL_A), ld(SL_A)}, d, d, M, P->g_w_out, P->g_b_out));
     STEP(G.run(0, 0, M, d, d, g1m, W(P->w_out, P->w_out16, P->ld_w_out16, d), at(SL_DA), ld(SL_DA), s16, ep0()));
     void* qkv = at(SL_QKV);
     void* dqkv = at(SL_DQKV);
     STEP(attn_bwd(qkv, ld(SL_QKV), col(qkv, s16, d), ld(SL_QKV), col(qkv, s16, 2 * d), ld(SL_QKV), at(SL_A), ld(SL_A), at(SL_DA),
                   ld(SL_DA), at(SL_LSE1), at(SL_DELTA), dqkv, ld(SL_DQKV), col(dqkv, s16, d), ld(SL_DQKV), col(dqkv, s16, 2 * d),
                   ld(SL_DQKV), B, H, T, T, dh, g->causal, scale, p, seed(S_SA_P), stream));
-    wgrad(Mat{dqkv, ld(SL_DQKV)}, s16 ? Mat{x16, ldx16} : Mat{x, d}, 3 * d, d, M, P->g_w_in, P->g_b_in);
+    STEP(wgrad(Mat{dqkv, ld(SL_DQKV)}, s16 ? Mat{x16, ldx16} : Mat{x, d}, 3 * d, d, M, P->g_w_in, P->g_b_in));
     STEP(flush(false));
     ep = ep0();
     ep.addend = at(SL_G1); ep.ld_addend = d;

@@ -532,8 +532,11 @@ def linear_dgrad(dy, w, out=None, addend=None, gelu_pre=None, drop_p=0.0, seed=0
 # them (caller-owned outputs) and wgrad_flush() -- called by the engine at the end of a block's backward -- hands them to
 # the lane in ONE hand-over; with GROUP_WGRADS on, the exact-fp32 ones go out as launches of up to GEMM_GROUP_MAX
 # products each (capdec_gemm_grouped: one chip-filling, unsplit grid).
-GROUP_WGRADS = os.environ.get("CAPDEC_GROUP_WGRADS", "1") == "1"
-GROUP_TILE = (0, 0)   # block tile of the grouped launches ((0, 0) = the library's default, 64 x 64)
+# Off by default: measured at C2 with the one-call layer plans, single launches under the tuned plans, handed over at two
+# points inside a layer, run the step in 14.64 ms against 14.93 with one grouped launch per layer (profiles/r03_grouped_gemm.txt)
+GROUP_WGRADS = os.environ.get("CAPDEC_GROUP_WGRADS", "0") == "1"
+# block tile of the grouped launches ((0, 0) = the library's default, 64 x 64); CAPDEC_GROUP_TILE=128x64 for experiments
+GROUP_TILE = tuple(int(v) for v in os.environ.get("CAPDEC_GROUP_TILE", "0x0").split("x"))
 _WGRAD_QUEUE = []
 
 

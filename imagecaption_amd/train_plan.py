@@ -10,6 +10,7 @@ plan: parameters after a step are bit-identical (tests/test_model_gpu.py).  Same
 (torch/nn/modules/transformer.py:1143-1199 as built at ref models.py:53-65; ref train.py:24-61).
 """
 import ctypes as C
+import os
 
 import torch
 
@@ -46,6 +47,7 @@ class LayerPlans:
         # (the op-by-op plan groups weight gradients only where it queues them: with a lane)
         grouped = bool(ops.GROUP_WGRADS and ops.SIDE is not None)
         g.group_wgrads, g.group_bm, g.group_bn = int(grouped), int(ops.GROUP_TILE[0]), int(ops.GROUP_TILE[1])
+        g.wgrad_flush_mask = int(os.environ.get("CAPDEC_WGRAD_FLUSH_MASK", "0"), 0)  # experiments; 0 = the library's default
         self.key = (B, T, S, H, bool(causal), float(drop_p), dtype, grouped, tuple(ops.GROUP_TILE))
         need = lib().capdec_train_layer_arena_bytes(C.byref(g))
         if need == 0:

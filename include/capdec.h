@@ -475,6 +475,9 @@ typedef struct capdec_train_geom {
     int B, T, S, H, d, dff, causal, dtype;
     float drop_p;
     int group_wgrads, group_bm, group_bn;
+    int wgrad_flush_mask; /* bit i: hand the queued weight gradients to the lane after the i-th one of the layer's backward
+                             (order: linear2, linear1, cross out_proj, cross q, cross k|v, self out_proj, self in_proj; the
+                             last one always hands over).  0 = the library's default (after linear1 and after cross k|v) */
 } capdec_train_geom;
 typedef struct capdec_train_layer {
     const void *w_in, *b_in, *w_out, *b_out, *ln1_w, *ln1_b, *wc_in, *bc_in, *wc_out, *bc_out, *ln2_w, *ln2_b, *w1, *b1, *w2,

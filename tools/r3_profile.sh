@@ -9,6 +9,9 @@ timeout -k 10 400 rocprofv3 --kernel-trace -d $O/r3e_prof_fp32 -o trace -- pytho
 python tools/rocpd_stats.py $(ls $O/r3e_prof_fp32/*.db | head -1) --timed > $O/r3e_stats_fp32.txt || exit 1
 timeout -k 10 400 rocprofv3 --kernel-trace -d $O/r3e_prof_c3 -o trace -- python3 bench.py --config c3 --dtype bf16s --steps 6 --warmup 2 --no-cpu-baseline --no-decode --no-modes --no-legs > $O/r3e_bench_c3_prof.json 2> $O/r3e_bench_c3_prof.err || exit 1
 python tools/rocpd_stats.py $(ls $O/r3e_prof_c3/*.db | head -1) --timed > $O/r3e_stats_c3.txt || exit 1
+timeout -k 10 400 rocprofv3 --kernel-trace -d $O/r3e_prof_c2s -o trace -- python3 bench.py --dtype bf16s --steps 20 --warmup 5 --no-cpu-baseline --no-decode --no-modes --no-legs > $O/r3e_bench_c2s_prof.json 2> $O/r3e_bench_c2s_prof.err || exit 1
+python tools/rocpd_stats.py $(ls $O/r3e_prof_c2s/*.db | head -1) --timed > $O/r3e_stats_c2s.txt || exit 1
+[ -n "$R3_SKIP_PMC" ] && { echo done; exit 0; }
 i=0
 for pmc in "GRBM_GUI_ACTIVE SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_INSTS_VALU SQ_VALU_MFMA_BUSY_CYCLES" \
            "SQ_INSTS_LDS SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE" "TCC_HIT_sum TCC_MISS_sum TCC_EA0_RDREQ_sum" "FETCH_SIZE" "WRITE_SIZE"; do

@@ -102,7 +102,7 @@ class CaptionTrainer:
         # each decoder layer as ONE C call per direction (train_plan.LayerPlans) wherever those plans cover the step;
         # False: the op-by-op launch plan of engine.layer_fwd / layer_bwd (same launches, same bits, more host time)
         self.one_call_layers = os.environ.get("CAPDEC_ONE_CALL_LAYERS", "1") == "1"
-        self._plans = None
+        self._plans, self._plan_cache = None, {}
         # data-parallel ranks must all run the same B*T (the loss gradient is pre-scaled by 1/(rows*world)): checked by
         # a collective that every rank issues on every step (parallel.EqualRowsGuard)
         self._rows_guard = EqualRowsGuard(process_group, dev)
@@ -133,7 +133,7 @@ class CaptionTrainer:
         for G in self.G_layers:  # these views are written by this trainer's launches only (engine._zero_query_grads)
             G["_cross_q_grads_zero"] = False
         self._kv_stack = None
-        self._plans = None
+        self._plans, self._plan_cache = None, {}
         fp = m.feature_projection
         self.P_proj = dict(zip(engine.PROJ_KEYS, [fp[0].weight, fp[0].bias, fp[1].weight, fp[1].bias, fp[4].weight,
                                                   fp[4].bias, fp[5].weight, fp[5].bias]))
@@ -161,12 +161,18 @@ class CaptionTrainer:
         key = (B, T, S, self.nhead, True, float(drop_p), dtype, bool(ops.GROUP_WGRADS and ops.SIDE is not None),
                tuple(ops.GROUP_TILE))
         if self._plans is None or self._plans.key != key:
-            self._plans = None  # (the old arenas go back to the allocator before the new ones are asked for)
-            try:
-                self._plans = train_plan.LayerPlans(self.P_layers, self.G_layers, B, T, S, self.nhead, True, drop_p, dtype,
-                                                    mem.device, copies)
-            except KeyError:  # a weight operand without a persistent bf16 copy: stay with the op-by-op plan
-                return None
+            # a few geometries stay planned side by side (training and evaluation steps alternate: dropout on / off, the
+            # last batch of an epoch is shorter); the oldest goes when a fifth one turns up
+            self._plans = self._plan_cache.get(key)
+            if self._plans is None:
+                if len(self._plan_cache) >= 4:
+                    self._plan_cache.pop(next(iter(self._plan_cache)))
+                try:
+                    self._plans = train_plan.LayerPlans(self.P_layers, self.G_layers, B, T, S, self.nhead, True, drop_p, dtype,
+                                                        mem.device, copies)
+                except KeyError:  # a weight operand without a persistent bf16 copy: stay with the op-by-op plan
+                    return None
+                self._plan_cache[key] = self._plans
         return self._plans
 
     # ---- one iteration of ref train.py:24-61 ---------------------------------------------------------

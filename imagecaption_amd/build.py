@@ -21,6 +21,10 @@ FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-fno-gpu-rdc", 
 FILE_FLAGS = {
     "attention_bf16.hip": ["-mllvm", "-amdgpu-mfma-vgpr-form=1"],
     "attention_f32_ring.hip": ["-mllvm", "-amdgpu-mfma-vgpr-form=1"],
+    # no SLP vectorisation in the files that hold the vector epilogue (gemm_common.h, epilogue_store_vec)
+    "gemm_bf16s_dma.hip": ["-fno-slp-vectorize"],
+    "gemm_bf16s_p8.hip": ["-fno-slp-vectorize"],
+    "gemm_f32.hip": ["-fno-slp-vectorize"],
 }
 
 

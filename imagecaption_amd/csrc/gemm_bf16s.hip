@@ -208,7 +208,8 @@ GemmPlan plan_gemm_bf16s(int M, int N, int K, const GemmForce& force) {
     if (force.bm) {
         const int split = force.split > 0 ? force.split : 1;
         const int ks = cdiv(cdiv(K, split), SBK) * SBK;
-        if (force.bm == 256) return GemmPlan{256, force.bn == 256 ? 256 : 128, SBK, cdiv(K, ks), ks};
+        if (force.bm == 256)  // k-tile field 32 with 256 x 256: the eight-phase kernel (gemm_bf16s_p8.hip)
+            return GemmPlan{256, force.bn == 256 ? 256 : 128, force.bn == 256 && force.bk == 32 ? 32 : SBK, cdiv(K, ks), ks};
         const int bm = force.bm == 128 && force.bn == 128 ? 128 : 64;
         return GemmPlan{bm, bm, force.bk ? force.bk : SBK, cdiv(K, ks), ks};
     }

@@ -104,8 +104,11 @@ __device__ __forceinline__ s16x4 pair_read_tr16_at(unsigned addr) {  // the same
     return v;
 }
 
+#ifndef CAPDEC_DMA_WPE
+#define CAPDEC_DMA_WPE 3
+#endif
 template <bool AKC, bool BKC, int NBUF, bool SPLITK>
-__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(NBUF == 1 ? (SPLITK ? 3 : 4) : 2)))
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(NBUF == 1 ? (SPLITK ? 3 : CAPDEC_DMA_WPE) : 2)))
 void gemm_bf16s_dma_kernel(GemmParams p) {
     constexpr int BM = 128, BN = BM, TM = 2, TN = 2;
     constexpr int NT = 256, WN = BN / (32 * TN);  // waves along N; two wave rows
@@ -341,6 +344,11 @@ void gemm_bf16s_dma_kernel(GemmParams p) {
     }
     if (do_colsum && tid < BM && m0 + tid < p.M) p.colsum[m0 + tid] = csum;
     if (p.ce_part) ce_tile_partials<TM, TN, BM, BN, WN, NT>(p, acc, reinterpret_cast<float*>(smem), m0, n0, tile_n, tid);
+    if (p.vec_epi) {  // the vector form of the epilogue (gemm_common.h): 32 rows at a time through 8 KB of LDS per wave
+        __syncthreads();  // every wave is done with whatever used the LDS last
+        epilogue_store_vec<TM, TN, 1>(p, acc, m0 + wrow, n0 + wcol, lane, reinterpret_cast<float*>(smem + wave * 8192));
+        return;
+    }
     epilogue_store<TM, TN>(p, acc, m0 + wrow, n0 + wcol, l31, half);
 }
 
@@ -636,10 +644,15 @@ static void launch_nbuf(const GemmParams& p, bool AKC, bool BKC, dim3 grid, hipS
     else hipLaunchKernelGGL((gemm_bf16s_dma_kernel<false, false, NBUF, SPLITK>), grid, block, 0, st, p);
 }
 
-// bm = 128: nbuf image pairs (1 or 2); bm = 256: the 256 x 256 pair kernel
+bool gemm_bf16s_p8_ok(const GemmParams& p, bool AKC, bool BKC);              // gemm_bf16s_p8.hip
+void launch_gemm_bf16s_p8(const GemmParams& p, dim3 grid, hipStream_t st);
+
+// bm = 128: nbuf image pairs (1 or 2); bm = 256: the 256 x 256 pair kernel, or (nbuf = 2, i.e. k-tile field 32, where
+// the operands allow it) the eight-phase kernel of gemm_bf16s_p8.hip
 void launch_gemm_bf16s_dma(const GemmParams& p, bool AKC, bool BKC, int bm, int nbuf, dim3 grid, hipStream_t st) {
     if (bm == 256) {
-        if (grid.z > 1) launch_pair<true>(p, AKC, BKC, grid, st);
+        if (nbuf == 2 && gemm_bf16s_p8_ok(p, AKC, BKC)) launch_gemm_bf16s_p8(p, grid, st);
+        else if (grid.z > 1) launch_pair<true>(p, AKC, BKC, grid, st);
         else launch_pair<false>(p, AKC, BKC, grid, st);
     } else if (nbuf == 2) launch_nbuf<2, true>(p, AKC, BKC, grid, st);
     else if (grid.z > 1) launch_nbuf<1, true>(p, AKC, BKC, grid, st);

@@ -35,6 +35,7 @@ struct GemmParams {
     // (row stride ldc2) -- one product writes the query block and, through the cache's row stride, the K | V block
     float* C2;
     int ldc2, n_split;
+    int vec_epi;            // the result can leave through the vector form of the epilogue (epilogue_vec_ok; set by capdec_gemm)
 };
 
 // capdec_gemm_grouped: the products of one launch, passed by value (kernel arguments)
@@ -187,13 +188,119 @@ __device__ __forceinline__ void epilogue_store(const GemmParams& p, const f32x16
                         if (p.act == CAPDEC_ACT_GELU) v = gelu_erf(v);
                         else if (gbwd) v *= gelu_erf_grad(has_add ? p.aux[o] : st[cur][e]);
                         if (p.drop.on()) v = p.drop.apply(v, (uint32_t)m * (uint32_t)p.N + (uint32_t)n);
-                        if (has_add) v += st[cur][e];
+                        if (has_add) {  // never contracted with the activation's last product (the vector form agrees bit for bit)
+#pragma clang fp contract(off)
+                            v = v + st[cur][e];
+                        }
                         if (p.c16) p.c16[(size_t)m * p.ldc16 + n] = (__bf16)v;
                         else p.C[o] = v;
                     }
                 }
             }
         }
+}
+
+// ---- the same epilogue in VECTOR form ---------------------------------------------------------------------------
+// The element form above is TM * TN * 16 unrolled element bodies (bounds test, option tests, 64-bit address, one
+// 4-byte store each): ~25 000 instructions of straight-line code for a 128 x 64 wave block.  Kernels with several
+// workgroups per CU hide it under their neighbours' products; the 256 x 256 block (one workgroup per CU) spent 39 of
+// its 129 us in it on a K = 1024 product.  Here the accumulators of a wave's (32 TM) x 64 block go through a
+// wave-private LDS region, 32 PI rows at a time, so that a lane then owns four CONSECUTIVE columns of a row: 16-byte
+// loads and stores, a compact loop, and the residual / GELU-input vectors of the next row group are requested before this
+// group's stores (loads never wait behind stores).  Same arithmetic per
+// element in the same order: v = acc + bias; pre = v; activation; dropout; + addend.
+// Needs N, ldc (ld_addend, ldc16) multiples of 4 and 16-byte aligned bases (8-byte for c16): epilogue_vec_ok.
+// `wl`: 32 PI x 32 TN floats of LDS that only this wave touches; unpadded -- the writes put a half-wave on 32 consecutive
+// columns of a row, the 16-byte reads are served in the 16-lane groups of ds_read_b128, which cover 16 distinct
+// slots of the 256-byte bank row.
+static inline bool epilogue_vec_ok(const GemmParams& p) {
+    auto al = [](const void* q, uintptr_t a) { return (reinterpret_cast<uintptr_t>(q) & (a - 1)) == 0; };
+    if (p.N % 4 || p.ldc % 4) return false;
+    if (p.c16 ? (p.ldc16 % 4 || !al(p.c16, 8)) : !al(p.C, 16)) return false;
+    if (p.bias && !al(p.bias, 16)) return false;
+    if (p.pre && !al(p.pre, 16)) return false;
+    if (p.addend && (p.ld_addend % 4 || !al(p.addend, 16))) return false;
+    if (p.act == CAPDEC_ACT_GELU_BWD && !al(p.aux, 16)) return false;
+    return true;
+}
+
+// Geometry of a wave's block for the vector epilogue: block row i (32 rows) starts at tile row
+// mbase + (i / PI) * pass_rows + (i % PI) * 32, block column j at nbase + j * col_stride.  The usual block is contiguous
+// (pass_rows = 32 PI, col_stride = 32); the eight-phase kernel deals rows and columns to its waves in two halves.
+template <int TM, int TN, int PI>
+__device__ __forceinline__ void epilogue_store_vec(const GemmParams& p, const f32x16 (&acc)[TM][TN], int mbase, int nbase,
+                                                   int lane, float* wl, int pass_rows = 32 * PI, int col_stride = 32) {
+    static_assert(TN == 1 || TN == 2, "a wave block is 32 or 64 columns wide");
+    constexpr int W = 32 * TN, LPR = W / 4, RPI = 64 / LPR;  // lanes per row, rows per wave-wide 16-byte access
+    constexpr int NIT = PI * 32 / RPI;                       // row groups per pass
+    // the options are wave-uniform run-time branches inside ONE loop body (one body per kernel keeps the code and the
+    // build small); every path stores exactly one result vector per row group, so the counted wait in front of the
+    // prefetched residual / GELU-input vectors never has to cover this group's stores
+    const bool PRE = p.pre != nullptr, DROP = p.drop.on(), ADD = p.addend != nullptr, C16 = p.c16 != nullptr;
+    const bool GELU = p.act == CAPDEC_ACT_GELU, GBWD = p.act == CAPDEC_ACT_GELU_BWD;
+    const int l31 = lane & 31, half = lane >> 5, c4 = (lane % LPR) * 4, rsub = lane / LPR;
+    const int n = nbase + (c4 & 31) + (c4 >> 5) * col_stride;
+    const bool n_ok = n < p.N;  // N % 4 == 0: all four columns or none
+    float4 b4 = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (p.bias && n_ok) b4 = *reinterpret_cast<const float4*>(p.bias + n);
+    const float4 zero4 = make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
+    for (int ps = 0; ps < TM / PI; ++ps) {
+#pragma unroll
+        for (int ii = 0; ii < PI; ++ii)
+#pragma unroll
+            for (int j = 0; j < TN; ++j)
+#pragma unroll
+                for (int r = 0; r < 16; ++r)
+                    wl[(ii * 32 + (r & 3) + 8 * (r >> 2) + 4 * half) * W + j * 32 + l31] = acc[ps * PI + ii][j][r];
+        const int m_first = mbase + ps * pass_rows + rsub;
+        float4 nadd = zero4, naux = zero4;
+        {
+            const bool ok = m_first < p.M && n_ok;
+            if (ADD && ok) nadd = *reinterpret_cast<const float4*>(p.addend + (size_t)m_first * p.ld_addend + n);
+            if (GBWD && ok) naux = *reinterpret_cast<const float4*>(p.aux + (size_t)m_first * p.ldc + n);
+        }
+#pragma unroll 1
+        for (int it = 0; it < NIT; ++it) {
+            const int m = m_first + it * RPI;
+            const float4 add = nadd, aux = naux;
+            float4 v = *reinterpret_cast<const float4*>(&wl[(it * RPI + rsub) * W + c4]);
+            if (it + 1 < NIT) {  // the next row group's reads, before this group's stores
+                const bool ok = m + RPI < p.M && n_ok;
+                if (ADD && ok) nadd = *reinterpret_cast<const float4*>(p.addend + (size_t)(m + RPI) * p.ld_addend + n);
+                if (GBWD && ok) naux = *reinterpret_cast<const float4*>(p.aux + (size_t)(m + RPI) * p.ldc + n);
+            }
+            if (m < p.M && n_ok) {
+                const size_t o = (size_t)m * p.ldc + n;
+                float e[4] = {v.x + b4.x, v.y + b4.y, v.z + b4.z, v.w + b4.w};
+                if (PRE) *reinterpret_cast<float4*>(p.pre + o) = make_float4(e[0], e[1], e[2], e[3]);
+                const float ax[4] = {aux.x, aux.y, aux.z, aux.w}, ad[4] = {add.x, add.y, add.z, add.w};
+                if (GELU) {
+#pragma unroll
+                    for (int c = 0; c < 4; ++c) e[c] = gelu_erf(e[c]);
+                } else if (GBWD) {
+#pragma unroll
+                    for (int c = 0; c < 4; ++c) e[c] *= gelu_erf_grad(ax[c]);
+                }
+                if (DROP) {
+#pragma unroll
+                    for (int c = 0; c < 4; ++c) e[c] = p.drop.apply(e[c], (uint32_t)m * (uint32_t)p.N + (uint32_t)(n + c));
+                }
+                if (ADD) {  // never contracted with the product in front of it (the element form agrees bit for bit)
+#pragma clang fp contract(off)
+#pragma unroll
+                    for (int c = 0; c < 4; ++c) e[c] = e[c] + ad[c];
+                }
+                if (C16) {
+                    typedef __bf16 bf16x4e __attribute__((ext_vector_type(4)));
+                    const bf16x4e h = {(__bf16)e[0], (__bf16)e[1], (__bf16)e[2], (__bf16)e[3]};
+                    *reinterpret_cast<bf16x4e*>(p.c16 + (size_t)m * p.ldc16 + n) = h;
+                } else {
+                    *reinterpret_cast<float4*>(p.C + o) = make_float4(e[0], e[1], e[2], e[3]);
+                }
+            }
+        }
+    }
 }
 
 // ---- fused cross-entropy pieces shared by the three GEMM kernels (same accumulator layout) ---------------------

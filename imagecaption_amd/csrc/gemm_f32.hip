@@ -14,6 +14,7 @@
 #include <unordered_map>
 
 #include "common.h"
+#include <cstdlib>
 #include "gemm_common.h"
 
 namespace capdec {
@@ -75,7 +76,9 @@ __device__ __forceinline__ void gemm_f32_tile(const GemmParams& p, const int wg_
     constexpr int A_V4 = BM * GBK / 4 / NT;
     constexpr int B_V4 = BN * GBK / 4 / NT;
     static_assert(A_V4 >= 1 && B_V4 >= 1, "tile too small for 256 threads");
-    __shared__ __attribute__((aligned(16))) float smem[2 * (A_SZ + B_SZ)];
+    constexpr int EPI_SZ = 4 * 32 * 32 * TN;  // the vector epilogue's wave-private regions (32 rows of a wave block each)
+    constexpr int SMEM_SZ = 2 * (A_SZ + B_SZ) > EPI_SZ ? 2 * (A_SZ + B_SZ) : EPI_SZ;
+    __shared__ __attribute__((aligned(16))) float smem[SMEM_SZ];
 
     const int tid = threadIdx.x;
     const int lane = tid & 63, wave = tid >> 6;
@@ -297,6 +300,11 @@ __device__ __forceinline__ void gemm_f32_tile(const GemmParams& p, const int wg_
         return;
     if (do_colsum && tid < BM && m0 + tid < p.M) p.colsum[m0 + tid] = csum;
     if (p.ce_part) ce_tile_partials<TM, TN, BM, BN>(p, acc, smem, m0, n0, tile_n, tid);
+    if (p.vec_epi) {  // the vector form of the epilogue (gemm_common.h): 32 rows of the wave block at a time through LDS
+        __syncthreads();  // every wave is done with whatever used the LDS last
+        epilogue_store_vec<TM, TN, 1>(p, acc, m0 + wrow, n0 + wcol, lane, smem + wave * (32 * 32 * TN));
+        return;
+    }
     epilogue_store<TM, TN>(p, acc, m0 + wrow, n0 + wcol, l31, half);
 }
 
@@ -611,6 +619,8 @@ extern "C" int capdec_gemm(int transA, int transB, int M, int N, int K, const vo
     }
     p.ksplit = pl.ksplit;
     p.tiles_n = cdiv(N, pl.bn);
+    const bool no_vec_epi = getenv("CAPDEC_NO_VEC_EPI") != nullptr;  // A/B hook (read per call): the element form everywhere
+    p.vec_epi = !no_vec_epi && epilogue_vec_ok(p);
     const bool vec = aligned16(A) && aligned16(B) && (lda % 4 == 0) && (ldb % 4 == 0);
     const bool AK = !transA, BKM = transB != 0;
     if (dtype == CAPDEC_BF16S) {

@@ -369,8 +369,8 @@ def _plan_candidates(dtype, M, N, K):
                 continue  # a chip-filling grid gains nothing from K slices; the ticket array holds 4096 tiles
             for bk in bks:
                 yield bm, bn, split, bk
-            if dtype == _capi.BF16S and bm == 128:  # the LDS-DMA kernel with two image pairs instead of one
-                yield bm, bn, split, 32
+            if dtype == _capi.BF16S and (bm == 128 or (bm, bn) == (256, 256)):
+                yield bm, bn, split, 32  # the 128 x 128 LDS-DMA kernel with two image pairs / the 256 x 256 eight-phase kernel
 
 
 def tune_gemm_plans(signatures, reps=4, min_gain=0.03, verbose=False):

@@ -95,7 +95,8 @@ def test_gemm_reads_bf16_operands_in_either_orientation(M, N, K, ta, tb):
         others = []
         try:  # every kernel family on the same ragged shapes: register-staged 64 / 128 (k-tile 16 = no DMA) / 256 x 128,
             # LDS-DMA 128 x 128 with one or two (k-tile 32) image pairs, LDS-DMA 256 x 256
-            for bm, bn, bk in ((64, 64, 0), (128, 128, 16), (256, 128, 0), (128, 128, 32), (128, 128, 0), (256, 256, 0)):
+            for bm, bn, bk in ((64, 64, 0), (128, 128, 16), (256, 128, 0), (128, 128, 32), (128, 128, 0), (256, 256, 0),
+                               (256, 256, 32)):  # k-tile 32 with 256 x 256: the eight-phase kernel (nt layout)
                 l.capdec_gemm_tune(bm, bn, 1, bk)
                 others.append(ops.gemm(a.to(DEV), b.to(DEV), ta, tb))
         finally:
@@ -129,7 +130,7 @@ def test_column_slice_of_a_wider_bf16_matrix_is_not_mistaken_for_zero_padding(ta
     with ops.compute_dtype("bf16s"):
         outs = [ops.gemm(wide(a), wide(b), ta, tb)]
         try:
-            for bm, bn, bk in ((128, 128, 0), (128, 128, 32), (256, 256, 0), (64, 64, 0)):  # forced DMA plans fall back too
+            for bm, bn, bk in ((128, 128, 0), (128, 128, 32), (256, 256, 0), (256, 256, 32), (64, 64, 0)):  # forced DMA plans fall back too
                 l.capdec_gemm_tune(bm, bn, 1, bk)
                 outs.append(ops.gemm(wide(a), wide(b), ta, tb))
         finally:
@@ -175,7 +176,7 @@ def test_forced_plans_splitk_epilogue_and_bias_gradient():
                 xs, ws_, bs, rs, dys, a2s = (t.to(DEV) for t in (x, w, b, r, dy, a2))
                 for bm, bn, split, bk in ((64, 64, 1, 0), (64, 64, 4, 0), (128, 128, 2, 0), (128, 128, 1, 32), (64, 64, 16, 0),
                                           (128, 128, 8, 32), (128, 128, 3, 16), (256, 128, 1, 0), (256, 128, 4, 0),
-                                          (256, 256, 1, 0), (256, 256, 4, 0)):
+                                          (256, 256, 1, 0), (256, 256, 4, 0), (256, 256, 1, 32), (256, 256, 4, 32), (256, 256, 3, 32)):
                     l.capdec_gemm_tune(bm, bn, split, bk)
                     ops._WS_NEED.clear()
                     outs = []
@@ -191,6 +192,49 @@ def test_forced_plans_splitk_epilogue_and_bias_gradient():
     finally:
         l.capdec_gemm_tune(0, 0, 0, 0)
         ops._WS_NEED.clear()
+
+
+@pytest.mark.parametrize("M,N,K,split", [(700, 520, 64, 1), (513, 300, 128, 1), (1024, 768, 1024, 1), (300, 1100, 1984, 1),
+                                          (2000, 777, 960, 3), (256, 256, 4160, 4), (5120, 1024, 1024, 1)])
+def test_eight_phase_256_block_is_bit_identical_to_the_128_block(M, N, K, split):
+    """The 256 x 256 eight-phase kernel (plan k-tile field 32) walks K in the same 16-deep steps and the same order as the
+    128 x 128 LDS-DMA kernel, so with the same K slices every output bit agrees -- one, two, odd and many k-tiles,
+    ragged edges, split-K, the fused epilogue, and the same bits again on a second and third launch (the kernel keeps
+    DMA requests in flight across barriers: a race would show as a changed tile)."""
+    ops = _ops()
+    from imagecaption_amd import _capi
+    from imagecaption_amd._capi import ACT_GELU, ACT_GELU_BWD
+    l = _capi.lib()
+    g = torch.Generator().manual_seed(M + N + K)
+    x, w = torch.randn(M, K, generator=g).to(DEV), (torch.randn(N, K, generator=g) / 8).to(DEV)
+    b, r = torch.randn(N, generator=g).to(DEV), torch.randn(M, N, generator=g).to(DEV)
+    try:
+        with ops.compute_dtype("bf16s"):
+            x16, w16 = ops.cast_bf16(x), ops.cast_bf16(w)
+            def variants():  # the epilogue's options, each against the element-form epilogue of the 128 x 128 kernel
+                pre = torch.empty(M, N, device=DEV)
+                o16 = torch.empty(M, (N + 7) // 8 * 8, device=DEV, dtype=torch.bfloat16)[:, :N]
+                return [ops.linear_fwd(x16, w16, b, act=ACT_GELU, addend=r),
+                        ops.gemm(x16, w16, 0, 1),
+                        ops.linear_fwd(x16, w16, b, drop_p=0.1, seed=77, addend=r),
+                        ops.linear_fwd(x16, w16, b, drop_p=0.3, seed=5),
+                        ops.linear_fwd(x16, w16, b, act=ACT_GELU, pre=pre, out=o16).float(), pre,
+                        ops.gemm(x16, w16, 0, 1, bias=b, aux=r, act=ACT_GELU_BWD, addend=pre),
+                        ops.gemm(x16, w16, 0, 1, aux=r, act=ACT_GELU_BWD, drop_p=0.1, seed=3)]
+            l.capdec_gemm_tune(128, 128, split, 0)
+            ops._WS_NEED.clear()
+            want = variants()
+            want_plain = want[1]
+            l.capdec_gemm_tune(256, 256, split, 32)
+            ops._WS_NEED.clear()
+            for _ in range(3):
+                for i, (got, w_) in enumerate(zip(variants(), want)):
+                    assert torch.equal(got, w_), i
+    finally:
+        l.capdec_gemm_tune(0, 0, 0, 0)
+        ops._WS_NEED.clear()
+    ref = r16(x.cpu()) @ r16(w.cpu()).T
+    assert relerr(want_plain, ref) < 2e-6 * math.sqrt(K)
 
 
 @pytest.mark.parametrize("rows,V,K", [(96, 1000, 64), (200, 30001, 72), (37, 257, 40)])
@@ -352,3 +396,50 @@ def test_layernorm_bf16_outputs_are_the_rounded_fp32_results(M, d):
             assert dd16.dtype == torch.bfloat16 and torch.equal(dd16, dd_ref.to(torch.bfloat16))
             ld = dd16.stride(0)
             assert torch.all(torch.as_strided(dd16, (M, ld), (ld, 1))[:, d:] == 0)
+
+
+@pytest.mark.parametrize("dt", ["bf16s", "fp32"])
+def test_vector_epilogue_equals_the_element_form_and_repeats(dt, monkeypatch):
+    """The vector form of the fused epilogue (accumulators through wave-private LDS, 16-byte loads / stores; gemm_common.h)
+    against the element form (CAPDEC_NO_VEC_EPI=1, read per call): every option, every layout, bit for bit, twice.
+    The GELU-backward cases at the large shape are the regression guard for a flaky wrong result that was traced to
+    SLP-vectorised epilogue arithmetic (v_exp_f32 feeding v_pk_mul_f32: wrong values in lanes 48-63 now and then);
+    the files that hold this epilogue are built with -fno-slp-vectorize (imagecaption_amd/build.py)."""
+    ops = _ops()
+    from imagecaption_amd._capi import ACT_GELU, ACT_GELU_BWD
+
+    def variants(M, N, K, ta, tb):
+        g = torch.Generator().manual_seed(M + N + K)
+        a = torch.randn((K, M) if ta else (M, K), generator=g).to(DEV)
+        b_ = (torch.randn((N, K) if tb else (K, N), generator=g) / 8).to(DEV)
+        bias, r = torch.randn(N, generator=g).to(DEV), torch.randn(M, N, generator=g).to(DEV)
+        with ops.compute_dtype(dt):
+            if dt == "bf16s":
+                a, b_ = ops.cast_bf16(a), ops.cast_bf16(b_)
+            pre = torch.empty(M, N, device=DEV)
+            o16 = torch.empty(M, (N + 7) // 8 * 8, device=DEV, dtype=torch.bfloat16)[:, :N]
+            res = [ops.gemm(a, b_, ta, tb), ops.gemm(a, b_, ta, tb, bias=bias),
+                   ops.gemm(a, b_, ta, tb, bias=bias, drop_p=0.1, seed=77, addend=r),
+                   ops.gemm(a, b_, ta, tb, bias=bias, act=ACT_GELU, pre=pre), pre.clone(),
+                   ops.gemm(a, b_, ta, tb, aux=r, act=ACT_GELU_BWD, drop_p=0.1, seed=3),
+                   ops.gemm(a, b_, ta, tb, bias=bias, aux=r, act=ACT_GELU_BWD, addend=pre)]
+            inpl = r.clone()
+            ops.gemm(a, b_, ta, tb, bias=bias, drop_p=0.1, seed=9, addend=inpl, out=inpl)  # the residual updated in place
+            res.append(inpl)
+            if dt == "bf16s":
+                res.append(ops.gemm(a, b_, ta, tb, bias=bias, out=o16).float())
+                res.append(ops.gemm(a, b_, ta, tb, bias=bias, act=ACT_GELU, pre=pre, out=o16).float())
+                res.append(ops.gemm(a, b_, ta, tb, aux=r, act=ACT_GELU_BWD, out=o16).float())
+            if ta:
+                cs = torch.empty(M, device=DEV)
+                res += [ops.gemm(a, b_, ta, tb, colsum=cs), cs]
+        return res
+
+    for (M, N, K), reps in (((5120, 2048, 512), 1), ((512, 512, 5120), 1), ((300, 260, 200), 1), ((12544, 1024, 512), 6)):
+        for ta, tb in ((0, 1), (0, 0), (1, 0)):
+            monkeypatch.setenv("CAPDEC_NO_VEC_EPI", "1")
+            want = variants(M, N, K, ta, tb)
+            monkeypatch.delenv("CAPDEC_NO_VEC_EPI")
+            for _ in range(reps + 1):
+                for i, (got, w_) in enumerate(zip(variants(M, N, K, ta, tb), want)):
+                    assert torch.equal(got, w_), (M, N, K, ta, tb, i)

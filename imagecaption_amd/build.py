@@ -24,6 +24,9 @@ FILE_FLAGS = {
     # no SLP vectorisation in the files that hold the vector epilogue (gemm_common.h, epilogue_store_vec)
     "gemm_bf16s_dma.hip": ["-fno-slp-vectorize"],
     "gemm_bf16s_p8.hip": ["-fno-slp-vectorize"],
+    "gemm_bf16s.hip": ["-fno-slp-vectorize"],
+    "gemm_bf16.hip": ["-fno-slp-vectorize"],
+    "gemm_f32x3.hip": ["-fno-slp-vectorize"],
     "gemm_f32.hip": ["-fno-slp-vectorize"],
 }
 

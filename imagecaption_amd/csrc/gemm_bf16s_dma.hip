@@ -607,6 +607,11 @@ void gemm_bf16s_pair_kernel(GemmParams p) {
     }
     if (do_colsum && tid < BM && m0 + tid < p.M) p.colsum[m0 + tid] = csum;
     if (p.ce_part) ce_tile_partials<TM, TN, BM, BN, WN, NT>(p, acc, reinterpret_cast<float*>(smem), m0, n0, tile_n, tid);
+    if (p.vec_epi) {  // one workgroup per CU: nothing hides the epilogue, so the vector form matters most here
+        __syncthreads();
+        epilogue_store_vec<TM, TN, 2>(p, acc, m0 + wrow, n0 + wcol, lane, reinterpret_cast<float*>(smem + wave * 16384));
+        return;
+    }
     epilogue_store<TM, TN>(p, acc, m0 + wrow, n0 + wcol, l31, half);
 }
 

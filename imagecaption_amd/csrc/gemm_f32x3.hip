@@ -244,6 +244,11 @@ void gemm_f32x3_kernel(GemmParams p) {
         return;
     if (do_colsum && tid < BM && m0 + tid < p.M) p.colsum[m0 + tid] = csum;
     if (p.ce_part) ce_tile_partials<TM, TN, BM, BN>(p, acc, reinterpret_cast<float*>(x3_smem), m0, n0, tile_n, tid);
+    if (p.vec_epi) {  // the vector form of the epilogue (gemm_common.h): 32 rows of the wave block at a time through LDS
+        __syncthreads();  // every wave is done with whatever used the LDS last
+        epilogue_store_vec<TM, TN, 1>(p, acc, m0 + wrow, n0 + wcol, lane, reinterpret_cast<float*>(x3_smem) + wave * (32 * 32 * TN));
+        return;
+    }
     epilogue_store<TM, TN>(p, acc, m0 + wrow, n0 + wcol, l31, half);
 }
 

@@ -650,13 +650,13 @@ static void launch_nbuf(const GemmParams& p, bool AKC, bool BKC, dim3 grid, hipS
 }
 
 bool gemm_bf16s_p8_ok(const GemmParams& p, bool AKC, bool BKC);              // gemm_bf16s_p8.hip
-void launch_gemm_bf16s_p8(const GemmParams& p, dim3 grid, hipStream_t st);
+void launch_gemm_bf16s_p8(const GemmParams& p, bool AKC, bool BKC, dim3 grid, hipStream_t st);
 
 // bm = 128: nbuf image pairs (1 or 2); bm = 256: the 256 x 256 pair kernel, or (nbuf = 2, i.e. k-tile field 32, where
 // the operands allow it) the eight-phase kernel of gemm_bf16s_p8.hip
 void launch_gemm_bf16s_dma(const GemmParams& p, bool AKC, bool BKC, int bm, int nbuf, dim3 grid, hipStream_t st) {
     if (bm == 256) {
-        if (nbuf == 2 && gemm_bf16s_p8_ok(p, AKC, BKC)) launch_gemm_bf16s_p8(p, grid, st);
+        if (nbuf == 2 && gemm_bf16s_p8_ok(p, AKC, BKC)) launch_gemm_bf16s_p8(p, AKC, BKC, grid, st);
         else if (grid.z > 1) launch_pair<true>(p, AKC, BKC, grid, st);
         else launch_pair<false>(p, AKC, BKC, grid, st);
     } else if (nbuf == 2) launch_nbuf<2, true>(p, AKC, BKC, grid, st);

@@ -326,7 +326,9 @@ __device__ __forceinline__ int ce_target(const GemmParams& p, int row, int V) {
 // columns: (max, sum exp(z - max), sum z).  32 rows at a time go through LDS as [row][BN + 1] (written by the two
 // waves that own them in the accumulator layout), then 8 threads per row reduce BN / 8 columns each.  `lds`: the
 // kernel's own (idle) LDS array, >= 32 * (BN + 1) floats.
-template <int TM, int TN, int BM, int BN, int WN = 2, int NT = 256>
+// MAP = 1: the eight-phase kernel's wave blocks (gemm_bf16s_p8.hip): 2 x 4 waves, block row i of wave row wr = tile rows
+// 128 (i / 2) + 64 wr + 32 (i % 2), block column j of wave column wc = tile columns 128 j + 32 wc.
+template <int TM, int TN, int BM, int BN, int WN = 2, int NT = 256, int MAP = 0>
 __device__ __forceinline__ void ce_tile_partials(const GemmParams& p, const f32x16 (&acc)[TM][TN], float* lds, int m0,
                                                  int n0, int tile_n, int tid) {
     // WN waves side by side along N (each 32 * TN columns), NT / 64 / WN wave rows (each 32 * TM rows); NT / 32
@@ -336,12 +338,13 @@ __device__ __forceinline__ void ce_tile_partials(const GemmParams& p, const f32x
     const int wr = wave / WN, wc = wave % WN;
 #pragma unroll
     for (int c = 0; c < WM * TM; ++c) {
-        const int cw = c / TM, ci = c % TM;
+        // chunk c = tile rows 32 c .. 32 c + 31: owned by wave row cw as its block row ci
+        const int cw = MAP == 1 ? (c >> 1) & 1 : c / TM, ci = MAP == 1 ? (c >> 2) * 2 + (c & 1) : c % TM;
         __syncthreads();
         if (wr == cw) {
 #pragma unroll
             for (int j = 0; j < TN; ++j) {
-                const int col = wc * (32 * TN) + j * 32 + l31;
+                const int col = MAP == 1 ? j * 128 + wc * 32 + l31 : wc * (32 * TN) + j * 32 + l31;
                 const int n = n0 + col;
                 const float b = (p.bias && n < p.N) ? p.bias[n] : 0.f;
 #pragma unroll
@@ -370,7 +373,7 @@ __device__ __forceinline__ void ce_tile_partials(const GemmParams& p, const f32x
             se += __shfl_xor(se, o, 64);
             sz += __shfl_xor(sz, o, 64);
         }
-        const int m = m0 + cw * (BM / WM) + ci * 32 + row;
+        const int m = MAP == 1 ? m0 + c * 32 + row : m0 + cw * (BM / WM) + ci * 32 + row;
         if (part == 0 && m < p.M) p.ce_part[(size_t)m * p.tiles_n + tile_n] = make_float4(mx, se, sz, 0.f);
     }
 }

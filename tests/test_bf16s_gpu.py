@@ -194,46 +194,62 @@ def test_forced_plans_splitk_epilogue_and_bias_gradient():
         ops._WS_NEED.clear()
 
 
+@pytest.mark.parametrize("ta,tb", [(0, 1), (0, 0), (1, 0), (1, 1)])
 @pytest.mark.parametrize("M,N,K,split", [(700, 520, 64, 1), (513, 300, 128, 1), (1024, 768, 1024, 1), (300, 1100, 1984, 1),
                                           (2000, 777, 960, 3), (256, 256, 4160, 4), (5120, 1024, 1024, 1)])
-def test_eight_phase_256_block_is_bit_identical_to_the_128_block(M, N, K, split):
+def test_eight_phase_256_block_is_bit_identical_to_the_128_block(M, N, K, split, ta, tb):
     """The 256 x 256 eight-phase kernel (plan k-tile field 32) walks K in the same 16-deep steps and the same order as the
-    128 x 128 LDS-DMA kernel, so with the same K slices every output bit agrees -- one, two, odd and many k-tiles,
-    ragged edges, split-K, the fused epilogue, and the same bits again on a second and third launch (the kernel keeps
-    DMA requests in flight across barriers: a race would show as a changed tile)."""
+    128 x 128 LDS-DMA kernel, so with the same K slices every output bit agrees -- all four operand layouts, one, two, odd
+    and many k-tiles, ragged edges, split-K, every option of the fused epilogue, and the same bits again on a second and
+    third launch (the kernel keeps DMA requests in flight across barriers: a race would show as a changed tile).  The
+    bias-gradient sums (k-major A) are grouped differently by the two kernels: compared against float64."""
     ops = _ops()
     from imagecaption_amd import _capi
     from imagecaption_amd._capi import ACT_GELU, ACT_GELU_BWD
     l = _capi.lib()
+    if (ta or not tb) and N % 8:
+        N = N // 8 * 8  # a k-major operand's rows are the output dimension: its pitch must cover it in 16-byte pieces anyway
+    if ta and M % 8:
+        M = M // 8 * 8
     g = torch.Generator().manual_seed(M + N + K)
-    x, w = torch.randn(M, K, generator=g).to(DEV), (torch.randn(N, K, generator=g) / 8).to(DEV)
+    x = torch.randn((K, M) if ta else (M, K), generator=g).to(DEV)
+    w = (torch.randn((N, K) if tb else (K, N), generator=g) / 8).to(DEV)
     b, r = torch.randn(N, generator=g).to(DEV), torch.randn(M, N, generator=g).to(DEV)
     try:
         with ops.compute_dtype("bf16s"):
             x16, w16 = ops.cast_bf16(x), ops.cast_bf16(w)
-            def variants():  # the epilogue's options, each against the element-form epilogue of the 128 x 128 kernel
+
+            def variants():  # the epilogue's options
                 pre = torch.empty(M, N, device=DEV)
                 o16 = torch.empty(M, (N + 7) // 8 * 8, device=DEV, dtype=torch.bfloat16)[:, :N]
-                return [ops.linear_fwd(x16, w16, b, act=ACT_GELU, addend=r),
-                        ops.gemm(x16, w16, 0, 1),
-                        ops.linear_fwd(x16, w16, b, drop_p=0.1, seed=77, addend=r),
-                        ops.linear_fwd(x16, w16, b, drop_p=0.3, seed=5),
-                        ops.linear_fwd(x16, w16, b, act=ACT_GELU, pre=pre, out=o16).float(), pre,
-                        ops.gemm(x16, w16, 0, 1, bias=b, aux=r, act=ACT_GELU_BWD, addend=pre),
-                        ops.gemm(x16, w16, 0, 1, aux=r, act=ACT_GELU_BWD, drop_p=0.1, seed=3)]
+                res = [ops.gemm(x16, w16, ta, tb, bias=b, act=ACT_GELU, addend=r),
+                       ops.gemm(x16, w16, ta, tb),
+                       ops.gemm(x16, w16, ta, tb, bias=b, drop_p=0.1, seed=77, addend=r),
+                       ops.gemm(x16, w16, ta, tb, bias=b, drop_p=0.3, seed=5),
+                       ops.gemm(x16, w16, ta, tb, bias=b, act=ACT_GELU, pre=pre, out=o16).float(), pre,
+                       ops.gemm(x16, w16, ta, tb, bias=b, aux=r, act=ACT_GELU_BWD, addend=pre),
+                       ops.gemm(x16, w16, ta, tb, aux=r, act=ACT_GELU_BWD, drop_p=0.1, seed=3)]
+                cs = None
+                if ta:
+                    cs = torch.empty(M, device=DEV)
+                    res.append(ops.gemm(x16, w16, ta, tb, colsum=cs))
+                return res, cs
             l.capdec_gemm_tune(128, 128, split, 0)
             ops._WS_NEED.clear()
-            want = variants()
+            want, _ = variants()
             want_plain = want[1]
             l.capdec_gemm_tune(256, 256, split, 32)
             ops._WS_NEED.clear()
             for _ in range(3):
-                for i, (got, w_) in enumerate(zip(variants(), want)):
-                    assert torch.equal(got, w_), i
+                got, cs = variants()
+                for i, (g_, w_) in enumerate(zip(got, want)):
+                    assert torch.equal(g_, w_), i
+                if cs is not None:
+                    assert relerr(cs, r16(x.cpu()).sum(0)) < 2e-5
     finally:
         l.capdec_gemm_tune(0, 0, 0, 0)
         ops._WS_NEED.clear()
-    ref = r16(x.cpu()) @ r16(w.cpu()).T
+    ref = (r16(x.cpu()).T if ta else r16(x.cpu())) @ (r16(w.cpu()).T if tb else r16(w.cpu()))
     assert relerr(want_plain, ref) < 2e-6 * math.sqrt(K)
 
 

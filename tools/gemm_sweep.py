@@ -53,7 +53,7 @@ for ta, tb, M, N, K in SHAPES:
     t = timeit(lambda: ops.gemm(a, b, ta, tb, out=out))
     res.append(("auto", t))
     for (bm, bn), sp, bk in itertools.product(CANDS, SPLITS, BKS if DT != "bf16s" else [0, 32]):
-        if DT == "bf16s" and bk == 32 and not (bm == 128 or (bm == 256 and bn == 256 and ta == 0 and tb == 1)): continue  # 32 = the two-image form of the 128 x 128 LDS-DMA kernel / the eight-phase 256 x 256 kernel (nt products)
+        if DT == "bf16s" and bk == 32 and not (bm == 128 or (bm == 256 and bn == 256)): continue  # 32 = the two-image form of the 128 x 128 LDS-DMA kernel / the eight-phase 256 x 256 kernel
         if sp > 1 and K // sp < 128: continue
         if sp > 1 and M * N * sp * 4 > (1 << 30): continue
         l.capdec_gemm_tune(bm, bn, sp, bk)

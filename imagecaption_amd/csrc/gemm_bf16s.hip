@@ -218,6 +218,9 @@ GemmPlan plan_gemm_bf16s(int M, int N, int K, const GemmForce& force) {
         const int bm = force.bm == 128 && force.bn == 128 ? 128 : 64;
         return GemmPlan{bm, bm, force.bk ? force.bk : SBK, cdiv(K, ks), ks};
     }
+    // at least three rounds of 256 x 256 tiles over the 256 CUs: the eight-phase kernel (measured on the C3 shapes:
+    // 1.1 - 1.3x the 128 x 128 form from 784 tiles up, behind it at 320; operands it cannot take fall back in the launcher)
+    if ((long)cdiv(M, 256) * cdiv(N, 256) >= 768 && K >= 256) return GemmPlan{256, 256, 32, 1, cdiv(K, SBK) * SBK};
     const int bm = (M >= 96 && N >= 96) ? 128 : 64;
     const long tiles = (long)cdiv(M, bm) * cdiv(N, bm);
     int split = 1;

@@ -400,7 +400,13 @@ def tune_gemm_plans(signatures, reps=4, min_gain=0.03, verbose=False):
             a, b = torch.randn((K if ta else M, lda), device=dev), torch.randn((N if tb else K, ldb), device=dev)
             if dtype == _capi.BF16S:  # the recorded strides are those of the bf16 copies
                 a, b = a.to(torch.bfloat16), b.to(torch.bfloat16)
+                if not ta:
+                    a[:, K:] = 0  # the casts' zero padding behind the reduction extent: what lets the LDS-DMA kernels
+                if tb:            # take a K that is not a multiple of 64 (the vocabulary gradient's K = V)
+                    b[:, K:] = 0
             a, b = a[:, :(M if ta else K)], b[:, :(K if tb else N)]
+            if dtype == _capi.BF16S:
+                a._capdec_zero_padded = b._capdec_zero_padded = True
             c = torch.empty((M, ldc), device=dev)[:, :N]
             ce = None
             if has_ce:  # the loaders that turn logits into dlogits are their own instantiation: time THAT kernel

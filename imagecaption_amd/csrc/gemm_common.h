@@ -357,7 +357,7 @@ __device__ __forceinline__ void ce_tile_partials(const GemmParams& p, const f32x
         float mx = -INFINITY, sz = 0.f;
 #pragma unroll
         for (int k = 0; k < CPT; ++k) {
-            const int col = part * CPT + k;
+            const int col = k * TPR + part;  // interleaved: the TPR threads of a row read consecutive words (no bank conflicts)
             const bool ok = n0 + col < p.N;
             v[k] = ok ? lds[row * LDR + col] : -INFINITY;
             mx = fmaxf(mx, v[k]);
@@ -367,7 +367,7 @@ __device__ __forceinline__ void ce_tile_partials(const GemmParams& p, const f32x
         for (int o = 1; o < TPR; o <<= 1) mx = fmaxf(mx, __shfl_xor(mx, o, 64));
         float se = 0.f;
 #pragma unroll
-        for (int k = 0; k < CPT; ++k) se += __expf(v[k] - mx);  // excluded columns: exp(-inf) = 0 (mx is finite: col 0 is in)
+        for (int k = 0; k < CPT; ++k) se += __expf(v[k] - mx);  // excluded columns: exp(-inf) = 0 (mx is finite: column 0 of the tile is in)
 #pragma unroll
         for (int o = 1; o < TPR; o <<= 1) {
             se += __shfl_xor(se, o, 64);

@@ -111,7 +111,11 @@ size_t capdec_gemm_workspace_bytes(int M, int N, int K);
 /* Tuning hook (process-global, not thread-safe): force block tile bm x bn in {64,128}^2 (CAPDEC_BF16S: 64 x 64,
  * 128 x 128, 256 x 128 or 256 x 256; other compute types run a forced 256-row tile as 128 x 128) and a split-K
  * factor (and k-tile bk in {0 = default, 16, 32}) for every following capdec_gemm call; bm = 0
- * restores the built-in cost model. */
+ * restores the built-in cost model.  CAPDEC_BF16S reads bk as a kernel choice: 128 x 128 with bk = 16 is the
+ * register-staged kernel, 0 / 32 the LDS-DMA kernel with one / two image pairs; 256 x 256 with bk = 32 is the
+ * eight-phase kernel (csrc/gemm_bf16s_p8.hip), with 0 the two-group "pair" kernel.
+ * Environment (read per call, an A/B hook): CAPDEC_NO_VEC_EPI=1 makes every product store through the element form of
+ * the fused epilogue instead of the vector form (same bits, slower; the eight-phase kernel then yields to the pair kernel). */
 int capdec_gemm_tune(int bm, int bn, int split, int bk);
 /* Tuned plans: record the (tile, split, k-tile) a caller MEASURED to be fastest for one product -- transposes,
  * shape and compute type -- on the device it runs on (the Python layer times the candidates once per shape,

@@ -210,12 +210,17 @@ def measured_mfma_peak(dtype):
     return fl.value / (e0.elapsed_time(e1) * 1e-3) / 1e12
 
 
-def vocab_traffic(config):
-    """HBM-side bytes per launch of the vocab GEMM from the committed PMC passes (profiles/), C2 only."""
-    path = os.path.join(ROOT, "profiles", "r02_vocab_gemm_traffic.json")
+def vocab_traffic(config, dtype="fp32"):
+    """HBM-side bytes per launch of the vocab GEMM from the committed PMC passes (profiles/): C2 fp32 and C3 bf16 storage."""
+    if config == "c3" and dtype == "bf16s":
+        path = os.path.join(ROOT, "profiles", "r03b_vocab_gemm_bf16s_traffic.json")
+    elif config == "c2" and dtype == "fp32":
+        path = os.path.join(ROOT, "profiles", "r02_vocab_gemm_traffic.json")
+        if not os.path.exists(path):
+            path = os.path.join(ROOT, "profiles", "r01_vocab_gemm_traffic.json")
+    else:
+        return None
     if not os.path.exists(path):
-        path = os.path.join(ROOT, "profiles", "r01_vocab_gemm_traffic.json")
-    if config != "c2" or not os.path.exists(path):
         return None
     with open(path) as f:
         return json.load(f)["traffic_bytes"]
@@ -380,7 +385,7 @@ def run_leg(name, dtype, steps, warmup, dev, rank, world, args, decode_images=0)
            "config": {"workload": LEG_WORKLOADS[name], "global_batch": cfg["batch"] * world, "seq_len": cfg["T"],
                       "memory_len": cfg["S"]},
            "step_tflops_algorithmic": train_flops_per_image(cfg) * value / 1e12}
-    out.update(roofline_block(cfg, dtype, agg, detail, with_peaks=False))
+    out.update(roofline_block(cfg, dtype, agg, detail, traffic=vocab_traffic(name, dtype), with_peaks=False))
     dec = None
     if decode_images:
         # decoding at this leg's dimensions (fp32, as the headline's decode numbers): for C3 the 30 000-word vocabulary
@@ -606,7 +611,7 @@ def main():
             "step_tflops_algorithmic": train_flops_per_image(cfg) * value / 1e12,
         }
         out.update(roofline_block(cfg, args.dtype, agg, detail,
-                                  traffic=vocab_traffic(args.config) if args.dtype == "fp32" else None))
+                                  traffic=vocab_traffic(args.config, args.dtype)))
         if args.detail:
             for k, d in sorted(detail.items(), key=lambda kv: -kv[1][3]):
                 print(f"{k:42s} n={d[0]:3d} {d[3] * 1e3:8.3f} ms  {d[1] / d[3] / 1e12:7.2f} TF/s"

@@ -79,12 +79,67 @@ struct P8Frag {
     }
 };
 
+// The vocabulary product's epilogue on this kernel: logits = acc + bias stored as fp32 (the vector form's loop), and on the
+// way the softmax partials of the fused cross-entropy (ref train.py:41-50; gemm_common.h ce_tile_partials is the generic
+// form: 8 chunks of 32 rows through LDS with two workgroup barriers each, ~125 us of an 870 us launch at one workgroup per
+// CU).  Here a row of the wave's block is 16 lanes x 4 columns in the vector loop: (max, sum exp(z - max), sum z) over
+// the wave's 64 columns by four shuffle steps each, left in LDS per (row, wave column); after ONE barrier 256 threads
+// combine the four wave columns of their row in a fixed order.  Deterministic; the partials' rounding differs from the
+// generic form's in the last bits (another summation order), which ce_finalize's own sum over the tiles absorbs.
+__device__ __forceinline__ void p8_epilogue_ce(const GemmParams& p, const f32x16 (&acc)[4][2], int m0, int n0, int wr, int wc,
+                                               int lane, float* wl, float4* part, int tile_n, int tid) {
+    const int l31 = lane & 31, half = lane >> 5, c4 = (lane & 15) * 4, rsub = lane >> 4;
+    const int n = n0 + wc * 32 + (c4 & 31) + (c4 >> 5) * 128;
+    const bool n_ok = n < p.N;  // N % 4 == 0 (epilogue_vec_ok): all four columns or none
+    float4 b4 = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (p.bias && n_ok) b4 = *reinterpret_cast<const float4*>(p.bias + n);
+#pragma unroll
+    for (int ps = 0; ps < 2; ++ps) {
+#pragma unroll
+        for (int ii = 0; ii < 2; ++ii)
+#pragma unroll
+            for (int j = 0; j < 2; ++j)
+#pragma unroll
+                for (int r = 0; r < 16; ++r)
+                    wl[(ii * 32 + (r & 3) + 8 * (r >> 2) + 4 * half) * 64 + j * 32 + l31] = acc[ps * 2 + ii][j][r];
+        const int row0 = ps * 128 + wr * 64 + rsub;  // tile row of this lane's first row group
+#pragma unroll 1
+        for (int it = 0; it < 16; ++it) {
+            const int trow = row0 + it * 4, m = m0 + trow;
+            const float4 v = *reinterpret_cast<const float4*>(&wl[(it * 4 + rsub) * 64 + c4]);
+            const float e[4] = {v.x + b4.x, v.y + b4.y, v.z + b4.z, v.w + b4.w};
+            float mx = n_ok ? fmaxf(fmaxf(e[0], e[1]), fmaxf(e[2], e[3])) : -INFINITY;
+#pragma unroll
+            for (int o = 1; o < 16; o <<= 1) mx = fmaxf(mx, __shfl_xor(mx, o, 64));
+            const float mref = mx == -INFINITY ? 0.f : mx;  // a wave block wholly past column N: no exp(-inf + inf)
+            float se = n_ok ? (__expf(e[0] - mref) + __expf(e[1] - mref)) + (__expf(e[2] - mref) + __expf(e[3] - mref)) : 0.f;
+            float sz = n_ok ? (e[0] + e[1]) + (e[2] + e[3]) : 0.f;
+#pragma unroll
+            for (int o = 1; o < 16; o <<= 1) {
+                se += __shfl_xor(se, o, 64);
+                sz += __shfl_xor(sz, o, 64);
+            }
+            if ((lane & 15) == 0) part[trow * 4 + wc] = make_float4(mx, se, sz, 0.f);
+            if (m < p.M && n_ok) *reinterpret_cast<float4*>(p.C + (size_t)m * p.ldc + n) = make_float4(e[0], e[1], e[2], e[3]);
+        }
+    }
+    __syncthreads();
+    if (tid < 256 && m0 + tid < p.M) {
+        const float4 q0 = part[tid * 4], q1 = part[tid * 4 + 1], q2 = part[tid * 4 + 2], q3 = part[tid * 4 + 3];
+        const float mx = fmaxf(fmaxf(q0.x, q1.x), fmaxf(q2.x, q3.x));  // finite: column 0 of the tile is inside the matrix
+        const float se = ((q0.y * __expf(q0.x - mx) + q1.y * __expf(q1.x - mx)) + q2.y * __expf(q2.x - mx)) + q3.y * __expf(q3.x - mx);
+        const float sz = ((q0.z + q1.z) + q2.z) + q3.z;
+        p.ce_part[(size_t)(m0 + tid) * p.tiles_n + tile_n] = make_float4(mx, se, sz, 0.f);
+    }
+}
+
 // ABL (diagnostic builds only): 1 = no DMA after the prologue, 2 = no MFMA, 3 = no fragment reads, 4 = no epilogue store
 template <bool AKC, bool BKC, bool SPLITK, int ABL = 0>
 __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2)))
 void gemm_bf16s_p8_kernel(GemmParams p) {
     constexpr int BM = 256, BN = 256, TM = 4, TN = 2, NT = 512, WN = 4;
-    __shared__ __attribute__((aligned(1024))) unsigned char smem[8 * P8_HALF];
+    // eight half-tile slots; behind them 16 KB where the waves leave their per-row cross-entropy partials (epilogue only)
+    __shared__ __attribute__((aligned(1024))) unsigned char smem[8 * P8_HALF + 256 * 4 * 16];
 
     const int tid = threadIdx.x;
     const int lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -397,12 +452,14 @@ void gemm_bf16s_p8_kernel(GemmParams p) {
             return;
     }
     if (do_colsum && tid < BM && m0 + tid < p.M) p.colsum[m0 + tid] = csum;
-    if (p.ce_part) {
-        ce_tile_partials<TM, TN, BM, BN, WN, NT, 1>(p, acc, reinterpret_cast<float*>(smem), m0, n0, tile_n, tid);
-    }
     __syncthreads();  // whatever used the LDS last is done before the waves write their private regions below
     if (ABL == 4) {
         if (acc[0][0][0] == 123.456f) p.C[0] = acc[1][1][3] + acc[2][0][5] + acc[3][1][7];
+        return;
+    }
+    if (p.ce_part) {  // the logits product: bias only, fp32 result (capdec_gemm checks), softmax partials per row and tile
+        p8_epilogue_ce(p, acc, m0, n0, wr, wc, lane, reinterpret_cast<float*>(smem + wave * 16384),
+                       reinterpret_cast<float4*>(smem + 8 * P8_HALF), tile_n, tid);
         return;
     }
     // one workgroup per CU: nothing else hides the epilogue, so it is the vector form (gemm_common.h); a pass = the

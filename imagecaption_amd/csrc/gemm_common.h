@@ -378,6 +378,59 @@ __device__ __forceinline__ void ce_tile_partials(const GemmParams& p, const f32x
     }
 }
 
+// The logits product's epilogue in vector form WITH the softmax partials of the fused cross-entropy (the vector
+// counterpart of ce_tile_partials + epilogue_store for the usual wave geometry: 2 x 2 waves, contiguous wave blocks).
+// logits = acc + bias are stored as fp32 by the vector loop; on the way a row of the wave block (LPR lanes x 4 columns)
+// gives (max, sum exp(z - max), sum z) over the wave's columns by log2(LPR) shuffle steps each, left in LDS per
+// (tile row, wave column); after ONE barrier a thread per tile row combines the two wave columns in a fixed order.
+// Deterministic; rounding differs from ce_tile_partials in the last bits (another summation order), which the finalize
+// kernel's sum over the tiles absorbs.  `part`: BM x 2 float4 of LDS outside the waves' private regions.
+template <int TM, int TN, int BM>
+__device__ __forceinline__ void epilogue_store_vec_ce(const GemmParams& p, const f32x16 (&acc)[TM][TN], int m0, int n0, int wrow,
+                                                      int wcol, int wc, int lane, float* wl, float4* part, int tile_n, int tid) {
+    static_assert(TN == 1 || TN == 2, "a wave block is 32 or 64 columns wide");
+    constexpr int W = 32 * TN, LPR = W / 4, RPI = 64 / LPR, NIT = 32 / RPI;
+    const int l31 = lane & 31, half = lane >> 5, c4 = (lane % LPR) * 4, rsub = lane / LPR;
+    const int n = n0 + wcol + c4;
+    const bool n_ok = n < p.N;  // N % 4 == 0 (epilogue_vec_ok): all four columns or none
+    float4 b4 = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (p.bias && n_ok) b4 = *reinterpret_cast<const float4*>(p.bias + n);
+#pragma unroll
+    for (int ps = 0; ps < TM; ++ps) {
+#pragma unroll
+        for (int j = 0; j < TN; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) wl[((r & 3) + 8 * (r >> 2) + 4 * half) * W + j * 32 + l31] = acc[ps][j][r];
+        const int row0 = wrow + ps * 32 + rsub;  // tile row of this lane's first row group
+#pragma unroll 1
+        for (int it = 0; it < NIT; ++it) {
+            const int trow = row0 + it * RPI, m = m0 + trow;
+            const float4 v = *reinterpret_cast<const float4*>(&wl[(it * RPI + rsub) * W + c4]);
+            const float e[4] = {v.x + b4.x, v.y + b4.y, v.z + b4.z, v.w + b4.w};
+            float mx = n_ok ? fmaxf(fmaxf(e[0], e[1]), fmaxf(e[2], e[3])) : -INFINITY;
+#pragma unroll
+            for (int o = 1; o < LPR; o <<= 1) mx = fmaxf(mx, __shfl_xor(mx, o, 64));
+            const float mref = mx == -INFINITY ? 0.f : mx;  // a wave block wholly past column N: no exp(-inf + inf)
+            float se = n_ok ? (__expf(e[0] - mref) + __expf(e[1] - mref)) + (__expf(e[2] - mref) + __expf(e[3] - mref)) : 0.f;
+            float sz = n_ok ? (e[0] + e[1]) + (e[2] + e[3]) : 0.f;
+#pragma unroll
+            for (int o = 1; o < LPR; o <<= 1) {
+                se += __shfl_xor(se, o, 64);
+                sz += __shfl_xor(sz, o, 64);
+            }
+            if ((lane % LPR) == 0) part[trow * 2 + wc] = make_float4(mx, se, sz, 0.f);
+            if (m < p.M && n_ok) *reinterpret_cast<float4*>(p.C + (size_t)m * p.ldc + n) = make_float4(e[0], e[1], e[2], e[3]);
+        }
+    }
+    __syncthreads();
+    if (tid < BM && m0 + tid < p.M) {
+        const float4 q0 = part[tid * 2], q1 = part[tid * 2 + 1];
+        const float mx = fmaxf(q0.x, q1.x);  // finite: column 0 of the tile is inside the matrix
+        const float se = q0.y * __expf(q0.x - mx) + q1.y * __expf(q1.x - mx);
+        p.ce_part[(size_t)(m0 + tid) * p.tiles_n + tile_n] = make_float4(mx, se, q0.z + q1.z, 0.f);
+    }
+}
+
 struct GemmPlan {
     int bm, bn, bk, split, ksplit;
 };

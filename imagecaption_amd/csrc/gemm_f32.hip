@@ -76,7 +76,8 @@ __device__ __forceinline__ void gemm_f32_tile(const GemmParams& p, const int wg_
     constexpr int A_V4 = BM * GBK / 4 / NT;
     constexpr int B_V4 = BN * GBK / 4 / NT;
     static_assert(A_V4 >= 1 && B_V4 >= 1, "tile too small for 256 threads");
-    constexpr int EPI_SZ = 4 * 32 * 32 * TN;  // the vector epilogue's wave-private regions (32 rows of a wave block each)
+    // the vector epilogue's wave-private regions (32 rows of a wave block each) + the cross-entropy combine area (BM x 2 float4)
+    constexpr int EPI_SZ = 4 * 32 * 32 * TN + BM * 2 * 4;
     constexpr int SMEM_SZ = 2 * (A_SZ + B_SZ) > EPI_SZ ? 2 * (A_SZ + B_SZ) : EPI_SZ;
     __shared__ __attribute__((aligned(16))) float smem[SMEM_SZ];
 
@@ -299,12 +300,16 @@ __device__ __forceinline__ void gemm_f32_tile(const GemmParams& p, const int wg_
                                                   reinterpret_cast<int*>(smem)))
         return;
     if (do_colsum && tid < BM && m0 + tid < p.M) p.colsum[m0 + tid] = csum;
-    if (p.ce_part) ce_tile_partials<TM, TN, BM, BN>(p, acc, smem, m0, n0, tile_n, tid);
     if (p.vec_epi) {  // the vector form of the epilogue (gemm_common.h): 32 rows of the wave block at a time through LDS
         __syncthreads();  // every wave is done with whatever used the LDS last
-        epilogue_store_vec<TM, TN, 1>(p, acc, m0 + wrow, n0 + wcol, lane, smem + wave * (32 * 32 * TN));
+        if (p.ce_part)  // the logits product: the softmax partials come out of the same loop
+            epilogue_store_vec_ce<TM, TN, BM>(p, acc, m0, n0, wrow, wcol, wave & 1, lane, smem + wave * (32 * 32 * TN),
+                                              reinterpret_cast<float4*>(smem + 4 * 32 * 32 * TN), tile_n, tid);
+        else
+            epilogue_store_vec<TM, TN, 1>(p, acc, m0 + wrow, n0 + wcol, lane, smem + wave * (32 * 32 * TN));
         return;
     }
+    if (p.ce_part) ce_tile_partials<TM, TN, BM, BN>(p, acc, smem, m0, n0, tile_n, tid);
     epilogue_store<TM, TN>(p, acc, m0 + wrow, n0 + wcol, l31, half);
 }
 

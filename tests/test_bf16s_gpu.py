@@ -292,6 +292,43 @@ def test_cross_entropy_around_the_bf16_vocabulary_product(rows, V, K):
     assert torch.all(torch.as_strided(d16, (rows, ldd), (ldd, 1))[:, V:] == 0)
 
 
+@pytest.mark.parametrize("rows,V,K", [(300, 1000, 128), (520, 30000, 64), (37, 260, 200), (1000, 2052, 192)])
+def test_cross_entropy_partials_of_the_eight_phase_kernel(rows, V, K):
+    """The 256 x 256 eight-phase kernel takes its softmax partials inside its vector epilogue (per-row shuffle reductions,
+    one barrier) instead of the generic chunked pass: logits bit-identical to the 128 x 128 kernel's, lse / loss equal to
+    float64 at the usual tolerance and to the generic form's within rounding; ragged last tile, repeated launches."""
+    ops = _ops()
+    from imagecaption_amd import _capi
+    l = _capi.lib()
+    g = torch.Generator().manual_seed(rows + V)
+    eps = 0.1
+    h, w, b = torch.randn(rows, K, generator=g), torch.randn(V, K, generator=g) / 4, torch.randn(V, generator=g)
+    y = torch.randint(0, V, (rows,), generator=g)
+    z = r16(h) @ r16(w).T + b.double()
+    lse_ref = torch.logsumexp(z, 1)
+    logp = z - lse_ref[:, None]
+    loss_ref = -(1 - eps) * logp[torch.arange(rows), y] - eps * logp.mean(1)
+    hs, ws_, bs, ys = h.to(DEV), w.to(DEV), b.to(DEV), y.to(DEV)
+    res = {}
+    try:
+        with ops.compute_dtype("bf16s"):
+            for plan in ((128, 128, 1, 0), (256, 256, 1, 32), (256, 256, 1, 32)):
+                l.capdec_gemm_tune(*plan)
+                ops._WS_NEED.clear()
+                part = torch.full((rows, ops.ce_tiles(rows, V, K), 4), float("nan"), device=DEV)
+                logits = ops.linear_fwd(hs, ws_, bs, ce_partials=part)
+                lse, loss = ops.ce_finalize(part, logits, ys, eps)
+                res.setdefault(plan, []).append((logits, lse, loss))
+    finally:
+        l.capdec_gemm_tune(0, 0, 0, 0)
+        ops._WS_NEED.clear()
+    (lg0, lse0, loss0), = res[(128, 128, 1, 0)]
+    (lg1, lse1, loss1), (lg2, lse2, loss2) = res[(256, 256, 1, 32)]
+    assert torch.equal(lg0, lg1) and torch.equal(lg1, lg2) and torch.equal(lse1, lse2) and torch.equal(loss1, loss2)
+    assert relerr(lg1, z) < 2e-5 and relerr(lse1, lse_ref) < 1e-5 and relerr(loss1, loss_ref) < 1e-5
+    assert relerr(lse1, lse0.double().cpu()) < 1e-6 and relerr(loss1, loss0.double().cpu()) < 1e-6
+
+
 def test_operand_contract_errors_are_reported():
     ops = _ops()
     from imagecaption_amd._capi import CapdecError

@@ -116,6 +116,7 @@ SIGNATURES = {
     "capdec_copy_f32_multi": (_i, [_vp, _i, _i, _vp]),
     "capdec_shift_captions": (_i, [_vp, _i, _i, _i, _vp, _vp, _vp]),
     "capdec_ce_dlogits_bf16": (_i, [_vp, _i, _vp, _vp, _i, _i, _f, _f, _vp, _i, _vp]),
+    "capdec_ce_dlogits_bf16_inplace": (_i, [_vp, _i, _vp, _vp, _i, _i, _f, _f, _vp]),
     "capdec_reduce_workspace_bytes": (_sz, []),
     "capdec_sum": (_i, [_vp, _sz, _f, _vp, _vp, _sz, _vp]),
     "capdec_sumsq": (_i, [_vp, _sz, _vp, _vp, _sz, _vp]),

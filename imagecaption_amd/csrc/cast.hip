@@ -117,6 +117,27 @@ __global__ __launch_bounds__(256) void ce_dlogits_bf16_kernel(const float* __res
     }
 }
 
+// the same for logits that are already bf16, in place (a thread owns the 8 elements it reads and rewrites)
+__global__ __launch_bounds__(256) void ce_dlogits_bf16_inplace_kernel(__bf16* z, int ld, const float* __restrict__ lse_in,
+                                                                       const int64_t* __restrict__ targets, int V, float eps, float gs) {
+    const int m = blockIdx.x;
+    __bf16* zr = z + (size_t)m * ld;
+    const float lse = lse_in[m], u = eps / (float)V, w = 1.f - eps;
+    int64_t y64 = targets[m];
+    const int y = (int)(y64 < 0 ? 0 : (y64 >= V ? V - 1 : y64));
+    for (int c0 = threadIdx.x * 8; c0 < ld; c0 += 256 * 8) {
+        const bf16x8c v = *reinterpret_cast<const bf16x8c*>(zr + c0);
+        bf16x8c o;
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+            float g = __expf((float)v[e] - lse) - u;
+            if (c0 + e == y) g -= w;
+            o[e] = (__bf16)(c0 + e < V ? g * gs : 0.f);
+        }
+        *reinterpret_cast<bf16x8c*>(zr + c0) = o;
+    }
+}
+
 }  // namespace capdec
 
 using namespace capdec;
@@ -223,4 +244,14 @@ extern "C" int capdec_ce_dlogits_bf16(const void* logits, int ldl, const void* l
     hipLaunchKernelGGL(ce_dlogits_bf16_kernel, dim3(M), dim3(256), 0, (hipStream_t)stream, (const float*)logits, ldl,
                        (const float*)lse, targets, V, eps, grad_scale, (__bf16*)dst, ldd, vec);
     return check_launch("capdec_ce_dlogits_bf16");
+}
+
+extern "C" int capdec_ce_dlogits_bf16_inplace(void* z16, int ld, const void* lse, const int64_t* targets, int M, int V, float eps,
+                                              float grad_scale, capdec_stream_t stream) {
+    CAPDEC_REQUIRE(z16 && lse && targets && M > 0 && V > 0, "capdec_ce_dlogits_bf16_inplace: bad arguments");
+    CAPDEC_REQUIRE(ld % 8 == 0 && ld >= V && aligned16(z16) && eps >= 0.f && eps < 1.f,
+                   "capdec_ce_dlogits_bf16_inplace: ld=%d must be a multiple of 8 that covers V, z16 16-byte aligned, 0 <= eps < 1", ld);
+    hipLaunchKernelGGL(ce_dlogits_bf16_inplace_kernel, dim3(M), dim3(256), 0, (hipStream_t)stream, (__bf16*)z16, ld,
+                       (const float*)lse, targets, V, eps, grad_scale);
+    return check_launch("capdec_ce_dlogits_bf16_inplace");
 }

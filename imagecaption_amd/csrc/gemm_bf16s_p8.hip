@@ -93,6 +93,18 @@ __device__ __forceinline__ void p8_epilogue_ce(const GemmParams& p, const f32x16
     const bool n_ok = n < p.N;  // N % 4 == 0 (epilogue_vec_ok): all four columns or none
     float4 b4 = make_float4(0.f, 0.f, 0.f, 0.f);
     if (p.bias && n_ok) b4 = *reinterpret_cast<const float4*>(p.bias + n);
+    // with the targets at hand the partial's fourth component carries the row's target logit (if its column is in this
+    // tile): the kernel staged the tile's 256 targets behind the partials (yt; -1 for rows past M)
+    const int* yt = reinterpret_cast<const int*>(part + 256 * 4);
+    const bool ZY = p.ce_y != nullptr, C16 = p.c16 != nullptr;
+    // which of this lane's 32 row groups hold their row's target column: one batch of LDS reads here instead of a
+    // dependent read in every turn of the store loop (a hit is rare: 4 columns out of V)
+    unsigned hit = 0;
+    if (ZY) {
+#pragma unroll
+        for (int g = 0; g < 32; ++g)
+            hit |= ((unsigned)(yt[(g >> 4) * 128 + wr * 64 + rsub + (g & 15) * 4] - n) < 4u ? 1u : 0u) << g;
+    }
 #pragma unroll
     for (int ps = 0; ps < 2; ++ps) {
 #pragma unroll
@@ -109,18 +121,18 @@ __device__ __forceinline__ void p8_epilogue_ce(const GemmParams& p, const f32x16
             const float4 v = *reinterpret_cast<const float4*>(&wl[(it * 4 + rsub) * 64 + c4]);
             const float e[4] = {v.x + b4.x, v.y + b4.y, v.z + b4.z, v.w + b4.w};
             float mx = n_ok ? fmaxf(fmaxf(e[0], e[1]), fmaxf(e[2], e[3])) : -INFINITY;
-#pragma unroll
-            for (int o = 1; o < 16; o <<= 1) mx = fmaxf(mx, __shfl_xor(mx, o, 64));
+            mx = group_max<16>(mx);
             const float mref = mx == -INFINITY ? 0.f : mx;  // a wave block wholly past column N: no exp(-inf + inf)
             float se = n_ok ? (__expf(e[0] - mref) + __expf(e[1] - mref)) + (__expf(e[2] - mref) + __expf(e[3] - mref)) : 0.f;
             float sz = n_ok ? (e[0] + e[1]) + (e[2] + e[3]) : 0.f;
-#pragma unroll
-            for (int o = 1; o < 16; o <<= 1) {
-                se += __shfl_xor(se, o, 64);
-                sz += __shfl_xor(sz, o, 64);
-            }
+            se = group_sum<16>(se);
+            sz = group_sum<16>(sz);
             if ((lane & 15) == 0) part[trow * 4 + wc] = make_float4(mx, se, sz, 0.f);
-            if (m < p.M && n_ok) *reinterpret_cast<float4*>(p.C + (size_t)m * p.ldc + n) = make_float4(e[0], e[1], e[2], e[3]);
+            if ((hit >> (ps * 16 + it)) & 1u) {  // the one lane that holds the row's target column overwrites the zero (a wave's LDS writes land in order)
+                const int yr = yt[trow] - n;     // 0..3 (then n_ok: targets are < N)
+                reinterpret_cast<float*>(&part[trow * 4 + wc])[3] = yr == 0 ? e[0] : yr == 1 ? e[1] : yr == 2 ? e[2] : e[3];
+            }
+            if (m < p.M && n_ok) ce_store4(p, m, n, e, C16);
         }
     }
     __syncthreads();
@@ -129,7 +141,7 @@ __device__ __forceinline__ void p8_epilogue_ce(const GemmParams& p, const f32x16
         const float mx = fmaxf(fmaxf(q0.x, q1.x), fmaxf(q2.x, q3.x));  // finite: column 0 of the tile is inside the matrix
         const float se = ((q0.y * __expf(q0.x - mx) + q1.y * __expf(q1.x - mx)) + q2.y * __expf(q2.x - mx)) + q3.y * __expf(q3.x - mx);
         const float sz = ((q0.z + q1.z) + q2.z) + q3.z;
-        p.ce_part[(size_t)(m0 + tid) * p.tiles_n + tile_n] = make_float4(mx, se, sz, 0.f);
+        p.ce_part[(size_t)(m0 + tid) * p.tiles_n + tile_n] = make_float4(mx, se, sz, ((q0.w + q1.w) + q2.w) + q3.w);
     }
 }
 
@@ -138,8 +150,9 @@ template <bool AKC, bool BKC, bool SPLITK, int ABL = 0>
 __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2)))
 void gemm_bf16s_p8_kernel(GemmParams p) {
     constexpr int BM = 256, BN = 256, TM = 4, TN = 2, NT = 512, WN = 4;
-    // eight half-tile slots; behind them 16 KB where the waves leave their per-row cross-entropy partials (epilogue only)
-    __shared__ __attribute__((aligned(1024))) unsigned char smem[8 * P8_HALF + 256 * 4 * 16];
+    // eight half-tile slots; behind them 16 KB where the waves leave their per-row cross-entropy partials and 1 KB for the
+    // tile's targets (epilogue only)
+    __shared__ __attribute__((aligned(1024))) unsigned char smem[8 * P8_HALF + 256 * 4 * 16 + 256 * 4];
 
     const int tid = threadIdx.x;
     const int lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -426,6 +439,12 @@ void gemm_bf16s_p8_kernel(GemmParams p) {
         k_tile(I0{}, t);
         if (t + 1 < nk) k_tile(I1{}, t + 1);
     }
+    // the logits product with targets: this tile's target ids, requested here so that the closing barriers hide the latency
+    constexpr bool CE = AKC && !SPLITK;  // capdec_gemm: ce_partials only with A row-major and without a K split
+    int ytgt = -1;
+    if constexpr (CE) {
+        if (p.ce_part && p.ce_y && tid < BM && m0 + tid < p.M) ytgt = ce_target(p, m0 + tid, p.N);
+    }
     if (!late) P8_BAR();  // the stagger, paid back
     P8_BAR();             // everyone is done with the images: the epilogue reuses the LDS
 #undef P8_BAR
@@ -452,15 +471,21 @@ void gemm_bf16s_p8_kernel(GemmParams p) {
             return;
     }
     if (do_colsum && tid < BM && m0 + tid < p.M) p.colsum[m0 + tid] = csum;
+    if constexpr (CE) {
+        if (p.ce_part && p.ce_y && tid < BM)  // the tile's targets, for p8_epilogue_ce
+            reinterpret_cast<int*>(smem + 8 * P8_HALF + 256 * 4 * 16)[tid] = ytgt;
+    }
     __syncthreads();  // whatever used the LDS last is done before the waves write their private regions below
     if (ABL == 4) {
         if (acc[0][0][0] == 123.456f) p.C[0] = acc[1][1][3] + acc[2][0][5] + acc[3][1][7];
         return;
     }
-    if (p.ce_part) {  // the logits product: bias only, fp32 result (capdec_gemm checks), softmax partials per row and tile
-        p8_epilogue_ce(p, acc, m0, n0, wr, wc, lane, reinterpret_cast<float*>(smem + wave * 16384),
-                       reinterpret_cast<float4*>(smem + 8 * P8_HALF), tile_n, tid);
-        return;
+    if constexpr (CE) {
+        if (p.ce_part) {  // the logits product: bias only (capdec_gemm checks), softmax partials per row and tile
+            p8_epilogue_ce(p, acc, m0, n0, wr, wc, lane, reinterpret_cast<float*>(smem + wave * 16384),
+                           reinterpret_cast<float4*>(smem + 8 * P8_HALF), tile_n, tid);
+            return;
+        }
     }
     // one workgroup per CU: nothing else hides the epilogue, so it is the vector form (gemm_common.h); a pass = the
     // wave's 64 rows of one A half (pass stride 128 rows), block columns 128 apart

@@ -24,7 +24,7 @@ struct GemmParams {
     int m_pad;         // tiles_m * BM
     int tiles_n;
     // label-smoothed cross-entropy fused into the vocabulary projection (ref train.py:41-50):
-    float4* ce_part;        // forward: per (row, column tile) softmax partials (max, sum exp(z - max), sum z, -)
+    float4* ce_part;        // forward: per (row, column tile) softmax partials (max, sum exp(z - max), sum z, target logit | 0: with ce_y)
     const float* ce_lse;    // backward: A holds the LOGITS; the A loaders turn them into dlogits on their way to LDS
     const int64_t* ce_y;    //   dlogits[row, col] = gs * (exp(z - lse[row]) - eps/V - (1 - eps) * [col == y[row]])
     float ce_gs, ce_u, ce_w;  // grad scale, eps / V, 1 - eps
@@ -303,6 +303,33 @@ __device__ __forceinline__ void epilogue_store_vec(const GemmParams& p, const f3
     }
 }
 
+// Butterfly reductions over aligned groups of L = 8 / 16 lanes as DPP moves (quad permutes, then the half-row and row
+// mirrors: VALU only), in place of ds_bpermute round trips through the LDS crossbar: every lane ends with the group's
+// result, bit-identical to the xor butterfly (after the quad steps a quad's lanes hold equal bits, so the partner a mirror
+// picks inside the other quad / half does not matter).
+template <int CTRL>
+__device__ __forceinline__ float dpp_move(float v) {
+    return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), CTRL, 0xF, 0xF, false));
+}
+template <int L>
+__device__ __forceinline__ float group_max(float v) {
+    static_assert(L == 8 || L == 16, "lane groups of 8 or 16");
+    v = fmaxf(v, dpp_move<0xB1>(v));   // quad_perm [1,0,3,2]
+    v = fmaxf(v, dpp_move<0x4E>(v));   // quad_perm [2,3,0,1]
+    v = fmaxf(v, dpp_move<0x141>(v));  // row_half_mirror
+    if (L == 16) v = fmaxf(v, dpp_move<0x140>(v));  // row_mirror
+    return v;
+}
+template <int L>
+__device__ __forceinline__ float group_sum(float v) {
+    static_assert(L == 8 || L == 16, "lane groups of 8 or 16");
+    v += dpp_move<0xB1>(v);
+    v += dpp_move<0x4E>(v);
+    v += dpp_move<0x141>(v);
+    if (L == 16) v += dpp_move<0x140>(v);
+    return v;
+}
+
 // ---- fused cross-entropy pieces shared by the three GEMM kernels (same accumulator layout) ---------------------
 // Backward: four consecutive vocabulary columns col0.. of logits row `row` -> their loss gradients.  `nvalid`
 // components (and only if row_ok) are inside the matrix; the rest stay the zero padding the tile expects.
@@ -320,6 +347,17 @@ __device__ __forceinline__ float4 ce_dlogits4(const GemmParams& p, float4 z, flo
 __device__ __forceinline__ int ce_target(const GemmParams& p, int row, int V) {
     const int64_t y = p.ce_y[row];
     return y < 0 ? 0 : (y >= V ? V - 1 : (int)y);  // out-of-range ids are clamped, as capdec_softmax_ce does
+}
+
+// the logits product's result vector: fp32 to C, or bf16 to c16 (the bf16-storage mode keeps its logits in bf16)
+__device__ __forceinline__ void ce_store4(const GemmParams& p, int m, int n, const float (&e)[4], bool c16) {
+    if (c16) {
+        typedef __bf16 bf16x4e __attribute__((ext_vector_type(4)));
+        const bf16x4e h = {(__bf16)e[0], (__bf16)e[1], (__bf16)e[2], (__bf16)e[3]};
+        *reinterpret_cast<bf16x4e*>(p.c16 + (size_t)m * p.ldc16 + n) = h;
+    } else {
+        *reinterpret_cast<float4*>(p.C + (size_t)m * p.ldc + n) = make_float4(e[0], e[1], e[2], e[3]);
+    }
 }
 
 // Forward: per row of this workgroup's BM x BN logits tile (acc + bias), the softmax partials over the tile's
@@ -353,8 +391,10 @@ __device__ __forceinline__ void ce_tile_partials(const GemmParams& p, const f32x
         }
         __syncthreads();
         const int row = tid / TPR, part = tid % TPR;
+        const int m = MAP == 1 ? m0 + c * 32 + row : m0 + cw * (BM / WM) + ci * 32 + row;
+        const int ycol = (p.ce_y && m < p.M) ? ce_target(p, m, p.N) - n0 : -1;  // the row's target column inside this tile, if any
         float v[CPT];
-        float mx = -INFINITY, sz = 0.f;
+        float mx = -INFINITY, sz = 0.f, zy = 0.f;
 #pragma unroll
         for (int k = 0; k < CPT; ++k) {
             const int col = k * TPR + part;  // interleaved: the TPR threads of a row read consecutive words (no bank conflicts)
@@ -362,19 +402,16 @@ __device__ __forceinline__ void ce_tile_partials(const GemmParams& p, const f32x
             v[k] = ok ? lds[row * LDR + col] : -INFINITY;
             mx = fmaxf(mx, v[k]);
             sz += ok ? v[k] : 0.f;
+            if (col == ycol) zy = v[k];
         }
-#pragma unroll
-        for (int o = 1; o < TPR; o <<= 1) mx = fmaxf(mx, __shfl_xor(mx, o, 64));
+        mx = group_max<TPR>(mx);
         float se = 0.f;
 #pragma unroll
         for (int k = 0; k < CPT; ++k) se += __expf(v[k] - mx);  // excluded columns: exp(-inf) = 0 (mx is finite: column 0 of the tile is in)
-#pragma unroll
-        for (int o = 1; o < TPR; o <<= 1) {
-            se += __shfl_xor(se, o, 64);
-            sz += __shfl_xor(sz, o, 64);
-        }
-        const int m = MAP == 1 ? m0 + c * 32 + row : m0 + cw * (BM / WM) + ci * 32 + row;
-        if (part == 0 && m < p.M) p.ce_part[(size_t)m * p.tiles_n + tile_n] = make_float4(mx, se, sz, 0.f);
+        se = group_sum<TPR>(se);
+        sz = group_sum<TPR>(sz);
+        if (p.ce_y) zy = group_sum<TPR>(zy);  // one thread of the row holds it, the others zero: exact
+        if (part == 0 && m < p.M) p.ce_part[(size_t)m * p.tiles_n + tile_n] = make_float4(mx, se, sz, zy);
     }
 }
 
@@ -395,6 +432,14 @@ __device__ __forceinline__ void epilogue_store_vec_ce(const GemmParams& p, const
     const bool n_ok = n < p.N;  // N % 4 == 0 (epilogue_vec_ok): all four columns or none
     float4 b4 = make_float4(0.f, 0.f, 0.f, 0.f);
     if (p.bias && n_ok) b4 = *reinterpret_cast<const float4*>(p.bias + n);
+    // with the targets at hand the partial's fourth component carries the row's target logit (if its column is in this
+    // tile): the tile's BM targets are staged behind the partials (workgroup-uniform branch, one more barrier)
+    int* yt = reinterpret_cast<int*>(part + BM * 2);
+    const bool ZY = p.ce_y != nullptr, C16 = p.c16 != nullptr;
+    if (ZY) {
+        if (tid < BM) yt[tid] = m0 + tid < p.M ? ce_target(p, m0 + tid, p.N) : -1;
+        __syncthreads();
+    }
 #pragma unroll
     for (int ps = 0; ps < TM; ++ps) {
 #pragma unroll
@@ -408,18 +453,18 @@ __device__ __forceinline__ void epilogue_store_vec_ce(const GemmParams& p, const
             const float4 v = *reinterpret_cast<const float4*>(&wl[(it * RPI + rsub) * W + c4]);
             const float e[4] = {v.x + b4.x, v.y + b4.y, v.z + b4.z, v.w + b4.w};
             float mx = n_ok ? fmaxf(fmaxf(e[0], e[1]), fmaxf(e[2], e[3])) : -INFINITY;
-#pragma unroll
-            for (int o = 1; o < LPR; o <<= 1) mx = fmaxf(mx, __shfl_xor(mx, o, 64));
+            mx = group_max<LPR>(mx);
             const float mref = mx == -INFINITY ? 0.f : mx;  // a wave block wholly past column N: no exp(-inf + inf)
             float se = n_ok ? (__expf(e[0] - mref) + __expf(e[1] - mref)) + (__expf(e[2] - mref) + __expf(e[3] - mref)) : 0.f;
             float sz = n_ok ? (e[0] + e[1]) + (e[2] + e[3]) : 0.f;
-#pragma unroll
-            for (int o = 1; o < LPR; o <<= 1) {
-                se += __shfl_xor(se, o, 64);
-                sz += __shfl_xor(sz, o, 64);
-            }
+            se = group_sum<LPR>(se);
+            sz = group_sum<LPR>(sz);
             if ((lane % LPR) == 0) part[trow * 2 + wc] = make_float4(mx, se, sz, 0.f);
-            if (m < p.M && n_ok) *reinterpret_cast<float4*>(p.C + (size_t)m * p.ldc + n) = make_float4(e[0], e[1], e[2], e[3]);
+            if (ZY) {  // the one lane that holds the row's target column overwrites the zero (a wave's LDS writes land in order)
+                const unsigned yr = (unsigned)(yt[trow] - n);  // 0..3 there (then n_ok: targets are < N)
+                if (yr < 4u) reinterpret_cast<float*>(&part[trow * 2 + wc])[3] = yr == 0 ? e[0] : yr == 1 ? e[1] : yr == 2 ? e[2] : e[3];
+            }
+            if (m < p.M && n_ok) ce_store4(p, m, n, e, C16);
         }
     }
     __syncthreads();
@@ -427,7 +472,7 @@ __device__ __forceinline__ void epilogue_store_vec_ce(const GemmParams& p, const
         const float4 q0 = part[tid * 2], q1 = part[tid * 2 + 1];
         const float mx = fmaxf(q0.x, q1.x);  // finite: column 0 of the tile is inside the matrix
         const float se = q0.y * __expf(q0.x - mx) + q1.y * __expf(q1.x - mx);
-        p.ce_part[(size_t)(m0 + tid) * p.tiles_n + tile_n] = make_float4(mx, se, q0.z + q1.z, 0.f);
+        p.ce_part[(size_t)(m0 + tid) * p.tiles_n + tile_n] = make_float4(mx, se, q0.z + q1.z, q0.w + q1.w);
     }
 }
 

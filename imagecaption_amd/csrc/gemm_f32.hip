@@ -77,7 +77,7 @@ __device__ __forceinline__ void gemm_f32_tile(const GemmParams& p, const int wg_
     constexpr int B_V4 = BN * GBK / 4 / NT;
     static_assert(A_V4 >= 1 && B_V4 >= 1, "tile too small for 256 threads");
     // the vector epilogue's wave-private regions (32 rows of a wave block each) + the cross-entropy combine area (BM x 2 float4)
-    constexpr int EPI_SZ = 4 * 32 * 32 * TN + BM * 2 * 4;
+    constexpr int EPI_SZ = 4 * 32 * 32 * TN + BM * 2 * 4 + BM;  // wave regions, CE partials, the tile's targets
     constexpr int SMEM_SZ = 2 * (A_SZ + B_SZ) > EPI_SZ ? 2 * (A_SZ + B_SZ) : EPI_SZ;
     __shared__ __attribute__((aligned(16))) float smem[SMEM_SZ];
 
@@ -571,7 +571,10 @@ extern "C" int capdec_gemm(int transA, int transB, int M, int N, int K, const vo
         p.c16 = (__bf16*)ep->c16;
         p.ldc16 = ep->ldc16;
         p.unpadded = ep->bf16_unpadded;
-        CAPDEC_REQUIRE(!p.c16 || (ep->ldc16 >= N && !ep->ce_partials), "capdec_gemm: c16 needs ldc16 >= N (and no ce_partials)");
+        CAPDEC_REQUIRE(!p.c16 || ep->ldc16 >= N, "capdec_gemm: c16 needs ldc16 >= N");
+        // bf16 logits: the loss's target logit must then come from the fp32 accumulators (the partials' 4th component)
+        CAPDEC_REQUIRE(!p.c16 || !ep->ce_partials || ep->ce_targets,
+                       "capdec_gemm: c16 with ce_partials needs ce_targets (the target logits leave through the partials)");
         p.ce_part = (float4*)ep->ce_partials;
         p.ce_lse = (const float*)ep->ce_lse;
         p.ce_y = ep->ce_targets;

@@ -72,20 +72,23 @@ __global__ __launch_bounds__(256) void ce_finalize_kernel(const float4* __restri
     float mx = -INFINITY;
     for (int t = lane; t < tiles; t += 64) mx = fmaxf(mx, pr[t].x);
     mx = wave_max(mx);
-    float se = 0.f, sz = 0.f;
+    float se = 0.f, sz = 0.f, zy = 0.f;
     for (int t = lane; t < tiles; t += 64) {
         const float4 q = pr[t];
         se += q.y * __expf(q.x - mx);
         sz += q.z;
+        zy += q.w;  // the target logit in exactly one tile, zero elsewhere (products run with ce_targets)
     }
     se = wave_sum(se);
     sz = wave_sum(sz);
+    zy = wave_sum(zy);
     if (lane == 0) {
         const float lse = mx + __logf(se);
         int64_t y = targets[row];
         y = y < 0 ? 0 : (y >= V ? V - 1 : y);
         if (lse_out) lse_out[row] = lse;
-        if (loss_rows) loss_rows[row] = lse - (1.f - eps) * logits[(size_t)row * ldl + y] - (eps / (float)V) * sz;
+        if (logits) zy = logits[(size_t)row * ldl + y];
+        if (loss_rows) loss_rows[row] = lse - (1.f - eps) * zy - (eps / (float)V) * sz;
     }
 }
 
@@ -188,8 +191,8 @@ extern "C" int capdec_softmax_ce(const void* logits, int ldl, const int64_t* tar
 
 extern "C" int capdec_ce_finalize(const void* partials, int tiles, const void* logits, int ldl, const int64_t* targets,
                                   void* lse, void* loss_rows, int M, int V, float eps, capdec_stream_t stream) {
-    CAPDEC_REQUIRE(partials && logits && targets && (lse || loss_rows), "capdec_ce_finalize: null pointer");
-    CAPDEC_REQUIRE(M > 0 && V > 0 && tiles > 0 && ldl >= V && aligned16(partials), "capdec_ce_finalize: bad shape M=%d V=%d "
+    CAPDEC_REQUIRE(partials && targets && (lse || loss_rows), "capdec_ce_finalize: null pointer");
+    CAPDEC_REQUIRE(M > 0 && V > 0 && tiles > 0 && (!logits || ldl >= V) && aligned16(partials), "capdec_ce_finalize: bad shape M=%d V=%d "
                    "tiles=%d (partials must be 16-byte aligned)", M, V, tiles);
     hipLaunchKernelGGL(ce_finalize_kernel, dim3((M + 3) / 4), dim3(256), 0, (hipStream_t)stream, (const float4*)partials,
                        tiles, (const float*)logits, ldl, targets, (float*)lse, (float*)loss_rows, M, V, eps);

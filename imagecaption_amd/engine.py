@@ -327,7 +327,7 @@ def proj_bwd(P, G, sv, dmem, dp, want_df=False):
     return ops.linear_dgrad(g1, P["0.weight"]) if want_df else None
 
 
-def head_fwd(P, x, dp, save, logits_out=None, ce_partials=None):
+def head_fwd(P, x, dp, save, logits_out=None, ce_partials=None, ce_targets=None):
     """output_layer (ref models.py:68-73): Linear, GELU, Dropout, Linear on x [M,d] -> logits [M,V].
     ``ce_partials``: the vocabulary product's epilogue also leaves the per-tile softmax partials of its logits there
     (label-smoothed cross-entropy fused into the product, ref train.py:41-50)."""
@@ -335,7 +335,7 @@ def head_fwd(P, x, dp, save, logits_out=None, ce_partials=None):
         if save is not None else None
     h = ops.linear_fwd(x, P["0.weight"], P["0.bias"], act=ACT_GELU, pre=u, drop_p=dp.p, seed=dp.seed(S_HEAD),
                        out=_hidden16(x.shape[0], P["0.weight"].shape[0], x.device))
-    logits = ops.linear_fwd(h, P["3.weight"], P["3.bias"], out=logits_out, ce_partials=ce_partials)
+    logits = ops.linear_fwd(h, P["3.weight"], P["3.bias"], out=logits_out, ce_partials=ce_partials, ce_targets=ce_targets)
     if save is not None:
         save.update(x=x, u=u, h=h)
     return logits

@@ -441,12 +441,13 @@ def tune_gemm_plans(signatures, reps=4, min_gain=0.03, verbose=False):
 
 
 def gemm(a, b, trans_a, trans_b, out=None, bias=None, addend=None, pre=None, aux=None, colsum=None, act=ACT_NONE,
-         drop_p=0.0, seed=0, ce_partials=None, ce=None):
+         drop_p=0.0, seed=0, ce_partials=None, ce=None, ce_targets=None):
     """out[M,N] = epilogue(op(a) @ op(b)); see capdec_gemm in include/capdec.h.
 
     ``ce_partials``: [M, ce_tiles(M, N, K)] x 4 floats receiving the per-tile softmax partials of the logits this
-    product writes (fused cross-entropy, forward).  ``ce = (lse, targets, eps, grad_scale)``: ``a`` holds LOGITS and
-    is read as dlogits (fused cross-entropy, backward; exact-fp32 compute type only)."""
+    product writes (fused cross-entropy, forward); with ``ce_targets`` (int64 [M]) their fourth component carries the
+    rows' fp32 target logits, which a bf16 ``out`` requires.  ``ce = (lse, targets, eps, grad_scale)``: ``a`` holds
+    LOGITS and is read as dlogits (fused cross-entropy, backward; exact-fp32 compute type only)."""
     if COMPUTE_DTYPE == _capi.BF16S:
         if ce is not None:
             raise _capi.CapdecError("gemm: the bf16-storage products take dlogits from ops.ce_dlogits_bf16, not ce=")
@@ -490,8 +491,8 @@ def gemm(a, b, trans_a, trans_b, out=None, bias=None, addend=None, pre=None, aux
     if COMPUTE_DTYPE == _capi.BF16S:
         ep.bf16_unpadded = _unpadded_bits(a, b, trans_a, trans_b, K)
     if out16:
-        if ce_partials is not None:
-            raise _capi.CapdecError("gemm: a bf16 result cannot be combined with ce_partials")
+        if ce_partials is not None and ce_targets is None:
+            raise _capi.CapdecError("gemm: a bf16 result with ce_partials needs ce_targets (the loss's target logits)")
         ep.c16, ep.ldc16 = ptr(out), out.stride(0)
     l = lib()
     if ce_partials is not None:
@@ -499,6 +500,12 @@ def gemm(a, b, trans_a, trans_b, out=None, bias=None, addend=None, pre=None, aux
         if tuple(ce_partials.shape) != (M, tiles, 4) or not ce_partials.is_contiguous():
             raise _capi.CapdecError(f"gemm: ce_partials must be a contiguous [M, {tiles}, 4] tensor")
         ep.ce_partials = ptr(_req(ce_partials, "gemm.ce_partials"))
+        if ce_targets is not None:
+            if _req(ce_targets, "gemm.ce_targets", torch.int64).numel() != M or not ce_targets.is_contiguous():
+                raise _capi.CapdecError("gemm: ce_targets must be a contiguous int64 tensor with one entry per row")
+            ep.ce_targets = ptr(ce_targets)
+    elif ce_targets is not None:
+        raise _capi.CapdecError("gemm: ce_targets goes with ce_partials")
     if ce is not None:
         lse, targets, eps, gs = ce
         rows = a.shape[0]
@@ -520,10 +527,11 @@ def gemm(a, b, trans_a, trans_b, out=None, bias=None, addend=None, pre=None, aux
     return out
 
 
-def linear_fwd(x, w, bias=None, out=None, act=ACT_NONE, pre=None, drop_p=0.0, seed=0, addend=None, ce_partials=None):
+def linear_fwd(x, w, bias=None, out=None, act=ACT_NONE, pre=None, drop_p=0.0, seed=0, addend=None, ce_partials=None,
+               ce_targets=None):
     """y = addend + dropout(act(x @ w.T + bias)); x [M,K], w [N,K]."""
     return gemm(x, w, False, True, out=out, bias=bias, addend=addend, pre=pre, act=act, drop_p=drop_p, seed=seed,
-                ce_partials=ce_partials)
+                ce_partials=ce_partials, ce_targets=ce_targets)
 
 
 def linear_dgrad(dy, w, out=None, addend=None, gelu_pre=None, drop_p=0.0, seed=0, ce=None):
@@ -940,14 +948,18 @@ def ce_tiles(M, V, K):
 
 
 def ce_finalize(partials, logits, targets, eps=0.1):
-    """(lse [M], loss_rows [M]) from the per-tile softmax partials the vocabulary product left (fused cross-entropy)."""
-    _mat(logits, "ce_finalize.logits")
+    """(lse [M], loss_rows [M]) from the per-tile softmax partials the vocabulary product left (fused cross-entropy).
+    bf16 ``logits`` (only their shape is used): the target logits are the partials' fourth components, i.e. the
+    product ran with ``ce_targets``."""
+    z16 = logits.dtype == torch.bfloat16
+    if not z16:
+        _mat(logits, "ce_finalize.logits")
     M, V = logits.shape
     targets = _req(targets, "ce_finalize.targets", torch.int64).contiguous()
     lse = torch.empty(M, dtype=torch.float32, device=logits.device)
     rows = torch.empty(M, dtype=torch.float32, device=logits.device)
-    check(lib().capdec_ce_finalize(ptr(_req(partials, "ce_finalize.partials")), partials.shape[1], ptr(logits),
-                                   logits.stride(0), ptr(targets), ptr(lse), ptr(rows), M, V, float(eps), stream()),
+    check(lib().capdec_ce_finalize(ptr(_req(partials, "ce_finalize.partials")), partials.shape[1], None if z16 else ptr(logits),
+                                   0 if z16 else logits.stride(0), ptr(targets), ptr(lse), ptr(rows), M, V, float(eps), stream()),
           "capdec_ce_finalize")
     return lse, rows
 
@@ -964,12 +976,20 @@ def ce_dlogits(logits, lse, targets, eps, grad_scale):
 
 def ce_dlogits_bf16(logits, lse, targets, eps, grad_scale):
     """The label-smoothed cross-entropy gradient of a logits block as a bf16 matrix (the operand form of the
-    bf16-storage products); the fp32 logits are left as they are."""
-    _mat(logits, "ce_dlogits_bf16.logits")
+    bf16-storage products); fp32 logits are left as they are, bf16 logits (a ``bf16_matrix`` the vocabulary product
+    wrote) are REPLACED by their gradient."""
     rows, V = logits.shape
     if _req(lse, "ce_dlogits_bf16.lse").numel() != rows or _req(targets, "ce_dlogits_bf16.targets", torch.int64).numel() != rows \
             or not (lse.is_contiguous() and targets.is_contiguous()):
         raise _capi.CapdecError("ce_dlogits_bf16: lse / targets must be contiguous with one entry per logits row")
+    if logits.dtype == torch.bfloat16:
+        _bf16_operand(logits, "ce_dlogits_bf16.logits")
+        if logits.stride(0) < _bf16_pitch(V):
+            raise _capi.CapdecError("ce_dlogits_bf16: bf16 logits need the row pitch of ops.bf16_matrix")
+        check(lib().capdec_ce_dlogits_bf16_inplace(ptr(logits), logits.stride(0), ptr(lse), ptr(targets), rows, V, float(eps),
+                                                    float(grad_scale), stream()), "capdec_ce_dlogits_bf16_inplace")
+        return _zero_padded(logits)
+    _mat(logits, "ce_dlogits_bf16.logits")
     ldd = _bf16_pitch(V)
     dst = torch.empty((rows, ldd), dtype=torch.bfloat16, device=logits.device)
     check(lib().capdec_ce_dlogits_bf16(ptr(logits), logits.stride(0), ptr(lse), ptr(targets), rows, V, float(eps),

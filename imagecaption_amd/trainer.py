@@ -95,6 +95,10 @@ class CaptionTrainer:
         self.gnorm_sq = torch.zeros(1, dtype=torch.float32, device=dev)
         self.reducer = BucketReducer(self.flat_g, self.bucket_ranges, process_group, overlap)
         self._logits = self._ce_part = self._embed_ws = None
+        # bf16 storage keeps the logits block in bf16 too (what a bf16-autocast F.linear hands the reference's loss): the
+        # vocabulary product writes half the bytes, the gradient pass rewrites the block in place; the LOSS is still
+        # the fp32 accumulators' (softmax partials and target logits leave through the product's epilogue)
+        self.logits_bf16 = dtype == "bf16s" and os.environ.get("CAPDEC_LOGITS_BF16", "1") == "1"
         # bf16 storage: the weight operands' copies, refreshed by one launch per step (ops.Bf16Copies) unless switched
         # off (then each weight is cast by the first product of the step that reads it: same values, ~40 launches)
         self._w16, self.one_launch_weight_casts = None, True
@@ -243,9 +247,14 @@ class CaptionTrainer:
                              True, dp, sv_stack, kv_stack=kv_stack, plans=self._layer_plans(B, T, S, mem, dp.p))
         # the logits block (B*T x V fp32, the step's largest tensor) is owned by the trainer: one allocation
         # for the run instead of a 100+ MB request to the caching allocator every step
-        if self._logits is None or tuple(self._logits.shape) != (B * T, self.P_head["3.weight"].shape[0]):
-            self._logits = torch.empty((B * T, self.P_head["3.weight"].shape[0]), dtype=torch.float32,
-                                       device=features.device)
+        z16 = self.logits_bf16 and self.dtype == "bf16s"
+        if self._logits is None or tuple(self._logits.shape) != (B * T, self.P_head["3.weight"].shape[0]) \
+                or (self._logits.dtype == torch.bfloat16) != z16:
+            if z16:
+                self._logits = ops.bf16_matrix(B * T, self.P_head["3.weight"].shape[0], features.device)
+            else:
+                self._logits = torch.empty((B * T, self.P_head["3.weight"].shape[0]), dtype=torch.float32,
+                                           device=features.device)
         # label-smoothed CE fused into the vocabulary product: its epilogue leaves per-tile softmax partials, a tiny
         # finalize gives lse / loss per row, and the two backward products read the LOGITS through the gradient
         # transform in their loaders -- the [B*T, V] block is written once and never rewritten (fp32; the other
@@ -254,9 +263,10 @@ class CaptionTrainer:
         tiles = ops.ce_tiles(B * T, V, K2)
         if self._ce_part is None or tuple(self._ce_part.shape) != (B * T, tiles, 4):
             self._ce_part = torch.empty((B * T, tiles, 4), dtype=torch.float32, device=features.device)
-        logits = engine.head_fwd(self.P_head, y, dp, sv_head, logits_out=self._logits, ce_partials=self._ce_part)
-        keep = logits.clone() if keep_logits else None
         targets = tgt_out.view(-1)
+        logits = engine.head_fwd(self.P_head, y, dp, sv_head, logits_out=self._logits, ce_partials=self._ce_part,
+                                 ce_targets=targets if z16 else None)
+        keep = (logits.float() if z16 else logits.clone()) if keep_logits else None
         lse, rows = ops.ce_finalize(self._ce_part, logits, targets, self.smooth)
         loss = ops.reduce_sum(rows, 1.0 / (B * T))
         nb = len(self.bucket_ranges)

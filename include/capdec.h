@@ -70,8 +70,11 @@ typedef struct capdec_epilogue {
     uint64_t drop_seed;
     /* label-smoothed cross-entropy fused into the vocabulary projection (ref train.py:41-50; all NULL = off):
      *   forward  (logits = h W^T + b, transA = 0, bias only): ce_partials [M, capdec_gemm_ce_tiles(M,N,K,dtype)]
-     *            float4 receives, per row and column tile, (max, sum exp(z - max), sum z, -) of the logits the
-     *            same epilogue writes to C; capdec_ce_finalize turns them into lse / loss rows.
+     *            float4 receives, per row and column tile, (max, sum exp(z - max), sum z, t) of the logits the
+     *            same epilogue writes to C; capdec_ce_finalize turns them into lse / loss rows.  With ce_targets set
+     *            (forward), t is the fp32 logit of the row's target if its column lies in the tile, else 0 -- which
+     *            is what lets the logits themselves leave as bf16 (c16 together with ce_partials REQUIRES
+     *            ce_targets): the loss is then still the fp32 accumulators' (capdec_ce_finalize with logits = NULL).
      *   backward (the two products that consume dlogits: dW = dlogits^T h with transA = 1, dh = dlogits W with
      *            transA = 0; transB = 0, dtype CAPDEC_F32): with ce_lse set, A holds the LOGITS and the A loaders
      *            compute dlogits[r,v] = ce_grad_scale * (exp(z - ce_lse[r]) - ce_eps/V - (1 - ce_eps)*[v == ce_targets[r]])
@@ -84,7 +87,8 @@ typedef struct capdec_epilogue {
     float ce_grad_scale;
     /* bf16 result: if c16 != NULL the epilogue's result is written there as bf16 (round to nearest even, row stride
      * ldc16 in bf16 elements) INSTEAD of to C (which may then be NULL; ldc still strides pre / aux) -- for results whose
-     * only readers take bf16 (the cross-attention K | V block of the bf16 storage path: capdec_attn_fwd_kv16). */
+     * only readers take bf16 (the cross-attention K | V block of the bf16 storage path: capdec_attn_fwd_kv16; the
+     * logits of the bf16 storage path, whose only reader is capdec_ce_dlogits_bf16_inplace). */
     void* c16;
     int ldc16;
     /* CAPDEC_BF16S operands whose reduction index is the contiguous one (A with transA = 0, B with transB = 1): a row
@@ -185,6 +189,14 @@ int capdec_shift_captions(const int64_t* captions, int ld, int B, int T1, int64_
 int capdec_cast_bf16_multi(const void* table_dev, int n, int total_blocks, capdec_stream_t stream);
 int capdec_ce_dlogits_bf16(const void* logits, int ldl, const void* lse, const int64_t* targets, int M, int V,
                            float eps, float grad_scale, void* dst, int ldd, capdec_stream_t stream);
+/* The same gradient for a logits block that is ALREADY bf16 (written by the vocabulary product through
+ * capdec_epilogue.c16, partials and target logits through ce_partials / ce_targets), in place: z16 [M, ld] bf16, ld a
+ * multiple of 8 that covers V, 16-byte aligned; z16[m][v] <- bf16(grad_scale * (exp(float(z16[m][v]) - lse[m]) - eps/V -
+ * (1 - eps) * [v == targets[m]])), padding columns V .. ld-1 zero.  Half the bytes of the fp32 logits on both sides of
+ * the loss (what torch.autocast's bf16 F.linear output gives the reference's loss, train.py:41-50, under bf16 autocast);
+ * the loss value itself comes from the fp32 partials. */
+int capdec_ce_dlogits_bf16_inplace(void* z16, int ld, const void* lse, const int64_t* targets, int M, int V, float eps,
+                                   float grad_scale, capdec_stream_t stream);
 
 /* ---- LayerNorm (+ optional GELU + dropout) ----------------------------------------------------
  * fwd: y = dropout(act(LN(x))), LN eps as given; mean/rstd [M] saved for backward (may be NULL).
@@ -342,7 +354,8 @@ int capdec_softmax_ce(const void* logits, int ldl, const int64_t* targets, void*
                       int M, int V, float eps, float grad_scale, capdec_stream_t stream);
 /* The fused form of the same loss (capdec_epilogue.ce_*): the vocabulary product's epilogue leaves per-tile softmax
  * partials, capdec_ce_finalize combines them per row -- lse[m] and loss_rows[m] as above (z_y is read from the
- * logits) -- and the backward products read the logits through the gradient transform.  capdec_gemm_ce_tiles: the
+ * fp32 logits; with logits = NULL it is the sum of the partials' fourth components, i.e. the product must have run
+ * with ce_targets) -- and the backward products read the logits through the gradient transform.  capdec_gemm_ce_tiles: the
  * number of column tiles (second dimension of the partials) capdec_gemm will use for this shape and dtype.
  * capdec_ce_dlogits: the same transform as a pass in place, for compute types whose loaders do not carry it
  * (CAPDEC_BF16 / CAPDEC_F32X3) and for callers that want dlogits materialised. */

@@ -8,6 +8,7 @@ tolerance is the fp32 one (2e-6 * sqrt(K)), not a loose "bf16 tolerance".  The b
 """
 import math
 
+import os
 import pytest
 import torch
 
@@ -327,6 +328,70 @@ def test_cross_entropy_partials_of_the_eight_phase_kernel(rows, V, K):
     assert torch.equal(lg0, lg1) and torch.equal(lg1, lg2) and torch.equal(lse1, lse2) and torch.equal(loss1, loss2)
     assert relerr(lg1, z) < 2e-5 and relerr(lse1, lse_ref) < 1e-5 and relerr(loss1, loss_ref) < 1e-5
     assert relerr(lse1, lse0.double().cpu()) < 1e-6 and relerr(loss1, loss0.double().cpu()) < 1e-6
+
+
+@pytest.mark.parametrize("rows,V,K", [(300, 1000, 128), (520, 30000, 64), (37, 260, 200), (1000, 2052, 192)])
+def test_bf16_logits_keep_the_fp32_loss(rows, V, K):
+    """bf16 storage keeps the logits block in bf16 (capdec_epilogue.c16 together with ce_partials and ce_targets): on
+    every kernel form the bf16 block is the RNE rounding of the fp32 block bit for bit, the softmax partials are the
+    fp32 form's bits, their fourth component is the row's fp32 target logit in exactly the tile that holds its column,
+    capdec_ce_finalize without logits gives the fp32 form's lse / loss bits, and the in-place gradient pass equals the
+    formula on the rounded logits (padding columns zero)."""
+    ops = _ops()
+    from imagecaption_amd import _capi
+    l = _capi.lib()
+    g = torch.Generator().manual_seed(rows + V + 1)
+    eps, gs = 0.1, 1.0 / rows
+    h, w, b = torch.randn(rows, K, generator=g), torch.randn(V, K, generator=g) / 4, torch.randn(V, generator=g)
+    y = torch.randint(0, V, (rows,), generator=g)
+    y[0], y[-1] = 0, V - 1
+    hs, ws_, bs, ys = h.to(DEV), w.to(DEV), b.to(DEV), y.to(DEV)
+    try:
+        with ops.compute_dtype("bf16s"):
+            for plan in ((128, 128, 1, 0), (256, 256, 1, 0), (256, 256, 1, 32), (256, 128, 1, 0)):
+                l.capdec_gemm_tune(*plan)
+                ops._WS_NEED.clear()
+                tiles = ops.ce_tiles(rows, V, K)
+                part = torch.full((rows, tiles, 4), float("nan"), device=DEV)
+                logits = ops.linear_fwd(hs, ws_, bs, ce_partials=part)
+                lse, loss = ops.ce_finalize(part, logits, ys, eps)
+                part16 = torch.full((rows, tiles, 4), float("nan"), device=DEV)
+                z16 = ops.bf16_matrix(rows, V, DEV)
+                ops.linear_fwd(hs, ws_, bs, out=z16, ce_partials=part16, ce_targets=ys)
+                assert torch.equal(z16, logits.to(torch.bfloat16)), plan
+                assert torch.equal(part16[:, :, :3], part[:, :, :3]), plan
+                bn = next(c for c in (256, 128, 64) if -(-V // c) == tiles)
+                want = torch.zeros(rows, tiles, device=DEV)
+                want[torch.arange(rows), ys // bn] = logits[torch.arange(rows), ys]
+                assert torch.equal(part16[:, :, 3], want), plan
+                lse16, loss16 = ops.ce_finalize(part16, z16, ys, eps)
+                assert torch.equal(lse16, lse) and torch.equal(loss16, loss), plan
+                zf = z16.float().double().cpu()
+                d16 = ops.ce_dlogits_bf16(z16, lse16, ys, eps, gs)
+                assert d16.data_ptr() == z16.data_ptr() and d16.dtype == torch.bfloat16
+                ref = torch.exp(zf - lse.double().cpu()[:, None]) - eps / V
+                ref[torch.arange(rows), y] -= 1 - eps
+                ref *= gs
+                assert bool(((d16.double().cpu() - ref).abs() <= 2 ** -8 * ref.abs() + 1e-5 * gs).all()), plan
+                ldd = d16.stride(0)
+                assert torch.all(torch.as_strided(d16, (rows, ldd), (ldd, 1))[:, V:] == 0)
+        # exact fp32: the target logits ride in the partials as well (vector and element form of the epilogue)
+        for env in (None, "1"):
+            if env:
+                os.environ["CAPDEC_NO_VEC_EPI"] = env
+            for plan in ((128, 128, 1, 0), (64, 64, 1, 0)):
+                l.capdec_gemm_tune(*plan)
+                tiles = ops.ce_tiles(rows, V, K)
+                part = torch.full((rows, tiles, 4), float("nan"), device=DEV)
+                logits = ops.linear_fwd(hs, ws_, bs, ce_partials=part, ce_targets=ys)
+                want = torch.zeros(rows, tiles, device=DEV)
+                bn = next(c for c in (256, 128, 64) if -(-V // c) == tiles)
+                want[torch.arange(rows), ys // bn] = logits[torch.arange(rows), ys]
+                assert torch.equal(part[:, :, 3], want), (env, plan)
+    finally:
+        os.environ.pop("CAPDEC_NO_VEC_EPI", None)
+        l.capdec_gemm_tune(0, 0, 0, 0)
+        ops._WS_NEED.clear()
 
 
 def test_operand_contract_errors_are_reported():

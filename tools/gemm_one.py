@@ -18,6 +18,9 @@ out = torch.empty(M, N, device="cuda")
 kw = {}
 if os.environ.get("GEMM_CE"):  # the vocabulary projection as the trainer launches it: bias + cross-entropy partials
     kw = dict(bias=torch.randn(N, device="cuda"), ce_partials=torch.empty(M, ops.ce_tiles(M, N, K), 4, device="cuda"))
+if os.environ.get("GEMM_CE") == "16":  # ... with the logits block kept in bf16 (the bf16 storage mode's default)
+    out = ops.bf16_matrix(M, N, "cuda")
+    kw["ce_targets"] = torch.randint(0, N, (M,), device="cuda")
 ops.gemm(a, b, ta, tb, out=out, **kw)
 e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
 e0.record()

@@ -213,7 +213,7 @@ def measured_mfma_peak(dtype):
 def vocab_traffic(config, dtype="fp32"):
     """HBM-side bytes per launch of the vocab GEMM from the committed PMC passes (profiles/): C2 fp32 and C3 bf16 storage."""
     if config == "c3" and dtype == "bf16s":
-        path = os.path.join(ROOT, "profiles", "r03b_vocab_gemm_bf16s_traffic.json")
+        path = os.path.join(ROOT, "profiles", "r03c_vocab_gemm_bf16s_traffic.json")
     elif config == "c2" and dtype == "fp32":
         path = os.path.join(ROOT, "profiles", "r02_vocab_gemm_traffic.json")
         if not os.path.exists(path):

@@ -330,13 +330,14 @@ def test_cross_entropy_partials_of_the_eight_phase_kernel(rows, V, K):
     assert relerr(lse1, lse0.double().cpu()) < 1e-6 and relerr(loss1, loss0.double().cpu()) < 1e-6
 
 
-@pytest.mark.parametrize("rows,V,K", [(300, 1000, 128), (520, 30000, 64), (37, 260, 200), (1000, 2052, 192)])
+@pytest.mark.parametrize("rows,V,K", [(300, 1000, 128), (520, 30000, 64), (37, 260, 200), (1000, 2052, 192), (130, 1003, 128)])
 def test_bf16_logits_keep_the_fp32_loss(rows, V, K):
     """bf16 storage keeps the logits block in bf16 (capdec_epilogue.c16 together with ce_partials and ce_targets): on
     every kernel form the bf16 block is the RNE rounding of the fp32 block bit for bit, the softmax partials are the
     fp32 form's bits, their fourth component is the row's fp32 target logit in exactly the tile that holds its column,
     capdec_ce_finalize without logits gives the fp32 form's lse / loss bits, and the in-place gradient pass equals the
-    formula on the rounded logits (padding columns zero)."""
+    formula on the rounded logits (padding columns zero).  V = 1003 (not a multiple of 4) takes the element form of the
+    epilogue on every kernel."""
     ops = _ops()
     from imagecaption_amd import _capi
     l = _capi.lib()

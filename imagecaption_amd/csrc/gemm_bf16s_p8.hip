@@ -145,6 +145,15 @@ __device__ __forceinline__ void p8_epilogue_ce(const GemmParams& p, const f32x16
     }
 }
 
+#ifdef CAPDEC_P8_DIAG
+// diagnostic builds only (tools/p8_stamps.py): s_memtime of wave 0 of every workgroup at kernel entry, first k-tile landed,
+// main loop done, stores drained
+__device__ unsigned long long g_p8_stamps[4096][4];
+#define P8_STAMP(i) do { if (tid == 0 && blockIdx.x < 4096) g_p8_stamps[blockIdx.x][i] = __builtin_amdgcn_s_memtime(); } while (0)
+#else
+#define P8_STAMP(i) do { } while (0)
+#endif
+
 // ABL (diagnostic builds only): 1 = no DMA after the prologue, 2 = no MFMA, 3 = no fragment reads, 4 = no epilogue store
 template <bool AKC, bool BKC, bool SPLITK, int ABL = 0>
 __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2)))
@@ -155,6 +164,7 @@ void gemm_bf16s_p8_kernel(GemmParams p) {
     __shared__ __attribute__((aligned(1024))) unsigned char smem[8 * P8_HALF + 256 * 4 * 16 + 256 * 4];
 
     const int tid = threadIdx.x;
+    P8_STAMP(0);
     const int lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int l31 = lane & 31, half = lane >> 5;
     const int wr = wave / WN, wc = wave % WN;
@@ -434,6 +444,7 @@ void gemm_bf16s_p8_kernel(GemmParams p) {
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     }
     P8_BAR();            // every wave's pieces of k-tile 0 have landed
+    P8_STAMP(1);
     if (late) P8_BAR();  // the stagger
     for (int t = 0; t < nk; t += 2) {
         k_tile(I0{}, t);
@@ -448,6 +459,7 @@ void gemm_bf16s_p8_kernel(GemmParams p) {
     if (!late) P8_BAR();  // the stagger, paid back
     P8_BAR();             // everyone is done with the images: the epilogue reuses the LDS
 #undef P8_BAR
+    P8_STAMP(2);
 
     float csum = 0.f;
     if constexpr (!AKC) {
@@ -490,6 +502,10 @@ void gemm_bf16s_p8_kernel(GemmParams p) {
     // one workgroup per CU: nothing else hides the epilogue, so it is the vector form (gemm_common.h); a pass = the
     // wave's 64 rows of one A half (pass stride 128 rows), block columns 128 apart
     epilogue_store_vec<TM, TN, 2>(p, acc, m0 + wr * 64, n0 + wc * 32, lane, reinterpret_cast<float*>(smem + wave * 16384), 128, 128);
+#ifdef CAPDEC_P8_DIAG
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    P8_STAMP(3);
+#endif
 }
 
 // the products the p8 kernel takes (beyond gemm_bf16s_dma_ok): a result the vector epilogue can store
@@ -516,3 +532,9 @@ void launch_gemm_bf16s_p8(const GemmParams& p, bool AKC, bool BKC, dim3 grid, hi
 }
 
 }  // namespace capdec
+
+#ifdef CAPDEC_P8_DIAG
+extern "C" int capdec_p8_stamps(void* dst, int n) {
+    return (int)hipMemcpyFromSymbol(dst, HIP_SYMBOL(capdec::g_p8_stamps), (size_t)n * 4 * sizeof(unsigned long long));
+}
+#endif

@@ -254,49 +254,92 @@ __device__ __forceinline__ void epilogue_store_vec(const GemmParams& p, const f3
                 for (int r = 0; r < 16; ++r)
                     wl[(ii * 32 + (r & 3) + 8 * (r >> 2) + 4 * half) * W + j * 32 + l31] = acc[ps * PI + ii][j][r];
         const int m_first = mbase + ps * pass_rows + rsub;
-        float4 nadd = zero4, naux = zero4;
-        {
-            const bool ok = m_first < p.M && n_ok;
-            if (ADD && ok) nadd = *reinterpret_cast<const float4*>(p.addend + (size_t)m_first * p.ld_addend + n);
-            if (GBWD && ok) naux = *reinterpret_cast<const float4*>(p.aux + (size_t)m_first * p.ldc + n);
-        }
+        if (!ADD && !GBWD) {
+            // no operand to fetch: a loop of its own WITHOUT the loop-carried loads below -- with them the compiler closes every turn
+            // with s_waitcnt vmcnt(0), which also waits for the turn's STORES (a round trip of ~1000 cycles each: 31 000 cycles for
+            // the 32 row groups of a 256 x 256 tile, against ~4 000 for 256 KB of stores in flight; tools/micro/store_rate.hip)
 #pragma unroll 1
-        for (int it = 0; it < NIT; ++it) {
-            const int m = m_first + it * RPI;
-            const float4 add = nadd, aux = naux;
-            float4 v = *reinterpret_cast<const float4*>(&wl[(it * RPI + rsub) * W + c4]);
-            if (it + 1 < NIT) {  // the next row group's reads, before this group's stores
-                const bool ok = m + RPI < p.M && n_ok;
-                if (ADD && ok) nadd = *reinterpret_cast<const float4*>(p.addend + (size_t)(m + RPI) * p.ld_addend + n);
-                if (GBWD && ok) naux = *reinterpret_cast<const float4*>(p.aux + (size_t)(m + RPI) * p.ldc + n);
+            for (int it = 0; it < NIT; ++it) {
+                const int m = m_first + it * RPI;
+                const float4 v = *reinterpret_cast<const float4*>(&wl[(it * RPI + rsub) * W + c4]);
+                if (m < p.M && n_ok) {
+                    const size_t o = (size_t)m * p.ldc + n;
+                    float e[4] = {v.x + b4.x, v.y + b4.y, v.z + b4.z, v.w + b4.w};
+                    if (PRE) *reinterpret_cast<float4*>(p.pre + o) = make_float4(e[0], e[1], e[2], e[3]);
+                    if (GELU) {
+#pragma unroll
+                        for (int c = 0; c < 4; ++c) e[c] = gelu_erf(e[c]);
+                    }
+                    if (DROP) {
+#pragma unroll
+                        for (int c = 0; c < 4; ++c) e[c] = p.drop.apply(e[c], (uint32_t)m * (uint32_t)p.N + (uint32_t)(n + c));
+                    }
+                    if (C16) {
+                        typedef __bf16 bf16x4e __attribute__((ext_vector_type(4)));
+                        const bf16x4e h = {(__bf16)e[0], (__bf16)e[1], (__bf16)e[2], (__bf16)e[3]};
+                        *reinterpret_cast<bf16x4e*>(p.c16 + (size_t)m * p.ldc16 + n) = h;
+                    } else {
+                        *reinterpret_cast<float4*>(p.C + o) = make_float4(e[0], e[1], e[2], e[3]);
+                    }
+                }
             }
-            if (m < p.M && n_ok) {
-                const size_t o = (size_t)m * p.ldc + n;
-                float e[4] = {v.x + b4.x, v.y + b4.y, v.z + b4.z, v.w + b4.w};
-                if (PRE) *reinterpret_cast<float4*>(p.pre + o) = make_float4(e[0], e[1], e[2], e[3]);
-                const float ax[4] = {aux.x, aux.y, aux.z, aux.w}, ad[4] = {add.x, add.y, add.z, add.w};
-                if (GELU) {
+            continue;
+        }
+        // A residual (addend) or GELU-input (aux) vector per row group.  Memory operations retire in order, so a wait for a
+        // fetched vector also waits for every store issued before the fetch: fetched one row group ahead of its use, each turn
+        // would wait for the previous turn's stores (~1000 cycles each).  So the vectors of G row groups are requested together,
+        // then those G groups are computed and stored with nothing to wait for: one store round trip per G groups.
+        constexpr int G = NIT < 4 ? NIT : 4;
+        static_assert(NIT % G == 0, "row groups per pass: a multiple of the fetch batch");
+#pragma unroll 1
+        for (int it0 = 0; it0 < NIT; it0 += G) {
+            typedef float f32x4v __attribute__((ext_vector_type(4)));
+            f32x4v nadd[G], naux[G];
 #pragma unroll
-                    for (int c = 0; c < 4; ++c) e[c] = gelu_erf(e[c]);
-                } else if (GBWD) {
+            for (int g = 0; g < G; ++g) {
+                const int mm = m_first + (it0 + g) * RPI;
+                const bool ok = mm < p.M && n_ok;
+                nadd[g] = naux[g] = f32x4v{0.f, 0.f, 0.f, 0.f};
+                if (ADD && ok) nadd[g] = *reinterpret_cast<const f32x4v*>(p.addend + (size_t)mm * p.ld_addend + n);
+                if (GBWD && ok) naux[g] = *reinterpret_cast<const f32x4v*>(p.aux + (size_t)mm * p.ldc + n);
+            }
+            // all of them are waited for HERE, on every path (a row group wholly outside the matrix skips its body: its vector
+            // would stay pending and every later reuse of its registers would draw a full wait, stores included)
 #pragma unroll
-                    for (int c = 0; c < 4; ++c) e[c] *= gelu_erf_grad(ax[c]);
-                }
-                if (DROP) {
+            for (int g = 0; g < G; ++g) asm volatile("" : "+v"(nadd[g]), "+v"(naux[g]));
 #pragma unroll
-                    for (int c = 0; c < 4; ++c) e[c] = p.drop.apply(e[c], (uint32_t)m * (uint32_t)p.N + (uint32_t)(n + c));
-                }
-                if (ADD) {  // never contracted with the product in front of it (the element form agrees bit for bit)
+            for (int g = 0; g < G; ++g) {
+                const int it = it0 + g, m = m_first + it * RPI;
+                const f32x4v add = nadd[g], aux = naux[g];
+                const float4 v = *reinterpret_cast<const float4*>(&wl[(it * RPI + rsub) * W + c4]);
+                if (m < p.M && n_ok) {
+                    const size_t o = (size_t)m * p.ldc + n;
+                    float e[4] = {v.x + b4.x, v.y + b4.y, v.z + b4.z, v.w + b4.w};
+                    if (PRE) *reinterpret_cast<float4*>(p.pre + o) = make_float4(e[0], e[1], e[2], e[3]);
+                    const float ax[4] = {aux.x, aux.y, aux.z, aux.w}, ad[4] = {add.x, add.y, add.z, add.w};
+                    if (GELU) {
+#pragma unroll
+                        for (int c = 0; c < 4; ++c) e[c] = gelu_erf(e[c]);
+                    } else if (GBWD) {
+#pragma unroll
+                        for (int c = 0; c < 4; ++c) e[c] *= gelu_erf_grad(ax[c]);
+                    }
+                    if (DROP) {
+#pragma unroll
+                        for (int c = 0; c < 4; ++c) e[c] = p.drop.apply(e[c], (uint32_t)m * (uint32_t)p.N + (uint32_t)(n + c));
+                    }
+                    if (ADD) {  // never contracted with the product in front of it (the element form agrees bit for bit)
 #pragma clang fp contract(off)
 #pragma unroll
-                    for (int c = 0; c < 4; ++c) e[c] = e[c] + ad[c];
-                }
-                if (C16) {
-                    typedef __bf16 bf16x4e __attribute__((ext_vector_type(4)));
-                    const bf16x4e h = {(__bf16)e[0], (__bf16)e[1], (__bf16)e[2], (__bf16)e[3]};
-                    *reinterpret_cast<bf16x4e*>(p.c16 + (size_t)m * p.ldc16 + n) = h;
-                } else {
-                    *reinterpret_cast<float4*>(p.C + o) = make_float4(e[0], e[1], e[2], e[3]);
+                        for (int c = 0; c < 4; ++c) e[c] = e[c] + ad[c];
+                    }
+                    if (C16) {
+                        typedef __bf16 bf16x4e __attribute__((ext_vector_type(4)));
+                        const bf16x4e h = {(__bf16)e[0], (__bf16)e[1], (__bf16)e[2], (__bf16)e[3]};
+                        *reinterpret_cast<bf16x4e*>(p.c16 + (size_t)m * p.ldc16 + n) = h;
+                    } else {
+                        *reinterpret_cast<float4*>(p.C + o) = make_float4(e[0], e[1], e[2], e[3]);
+                    }
                 }
             }
         }

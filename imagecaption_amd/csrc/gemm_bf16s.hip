@@ -218,9 +218,14 @@ GemmPlan plan_gemm_bf16s(int M, int N, int K, const GemmForce& force) {
         const int bm = force.bm == 128 && force.bn == 128 ? 128 : 64;
         return GemmPlan{bm, bm, force.bk ? force.bk : SBK, cdiv(K, ks), ks};
     }
-    // at least three rounds of 256 x 256 tiles over the 256 CUs: the eight-phase kernel (measured on the C3 shapes:
-    // 1.1 - 1.3x the 128 x 128 form from 784 tiles up, behind it at 320; operands it cannot take fall back in the launcher)
-    if ((long)cdiv(M, 256) * cdiv(N, 256) >= 768 && K >= 256) return GemmPlan{256, 256, 32, 1, cdiv(K, SBK) * SBK};
+    // the eight-phase 256 x 256 kernel (one workgroup per CU) wherever its tiles fill the rounds they take: from 640 tiles up, and
+    // from 160 up when the last round is at least 70 % full (measured with the store-streaming epilogue, nt products with K =
+    // 1024: ahead of the 128 x 128 forms at 240, 480, 640, 800 and 1176 tiles, behind them at 80 and at 320 = 1.25 rounds;
+    // operands it cannot take fall back in the launcher)
+    {
+        const long t = (long)cdiv(M, 256) * cdiv(N, 256), rounds = (t + 255) / 256;
+        if (K >= 256 && (t >= 640 || (t >= 160 && 10 * t >= 7 * 256 * rounds))) return GemmPlan{256, 256, 32, 1, cdiv(K, SBK) * SBK};
+    }
     const int bm = (M >= 96 && N >= 96) ? 128 : 64;
     const long tiles = (long)cdiv(M, bm) * cdiv(N, bm);
     int split = 1;

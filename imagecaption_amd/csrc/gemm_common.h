@@ -289,7 +289,7 @@ __device__ __forceinline__ void epilogue_store_vec(const GemmParams& p, const f3
         // fetched vector also waits for every store issued before the fetch: fetched one row group ahead of its use, each turn
         // would wait for the previous turn's stores (~1000 cycles each).  So the vectors of G row groups are requested together,
         // then those G groups are computed and stored with nothing to wait for: one store round trip per G groups.
-        constexpr int G = NIT < 4 ? NIT : 4;
+        constexpr int G = TN == 1 ? 2 : (NIT < 4 ? NIT : 4);  // (32-column wave blocks belong to the register-capped fp32 tiles: two at a time)
         static_assert(NIT % G == 0, "row groups per pass: a multiple of the fetch batch");
 #pragma unroll 1
         for (int it0 = 0; it0 < NIT; it0 += G) {
